@@ -1,0 +1,252 @@
+// Non-causal flash attention forward for head_dim 128 on gfx950 (replaces F.scaled_dot_product_attention +
+// the sbhd<->bhsd permutes + the head flatten, CleanGeneralDIT.py:181-203, :299-304).
+//
+// Workgroup = 8 waves = 256 query rows (32 per wave), KV tile = 64 keys, K and V tiles double-buffered in LDS
+// (register-staged: the next tile's global loads are issued before the current tile's MFMAs and written to LDS
+// after them, one barrier per tile).
+//
+// Per wave and KV tile (v_mfma_f32_32x32x16_bf16 only):
+//   S^T[key][q]  = K . Q^T          A = K rows (ds_read_b128, XOR-swizzled 256-B rows), B = Q (registers)
+//       -> the query sits on the LANE, its 64 scores in 2x16 registers of lanes l and l^32:
+//          row max / row sum are in-register reductions + one cross-lane exchange.
+//   O^T[d][q]   += V^T . P^T        B = P^T taken straight from the S^T accumulator registers (cvt to bf16, no
+//       lane movement; the k order inside a 16-step is permuted: element j of lane half h is key
+//       16s + 8(j>>2) + 4h + (j&3)), A = V^T read with ds_read_b64_tr_b16 in that same key order.
+//   O^T keeps the query on the lane too, so the online-softmax rescale is one per-lane scalar.
+//
+// Softmax in fp32 (exp2 with the scale folded in), P rounded to bf16 for the PV MFMA, row sum from the fp32 P.
+#include "drn_common.h"
+
+#define QROWS 256        // query rows per workgroup
+#define KVT 64           // keys per tile
+#define KBYTES (KVT * 256)
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+
+__device__ __forceinline__ bf16x4_t ds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(p));
+}
+
+__global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, bf16_t* __restrict__ O,
+    int heads, int64_t Sq, int64_t Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
+    int64_t bsv, int64_t bso, float scale_log2e, int nqb, int total) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * KBYTES];   // K0 K1 V0 V1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware order: each XCD walks consecutive (batch, head) pairs so the K/V stream of a head is L2-shared
+    int pid;
+    {
+        const int bid = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = bid & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int bh = pid / nqb;
+    const int qb = pid - bh * nqb;
+    const int b = bh / heads, head = bh - b * heads;
+    const int64_t q0 = (int64_t)qb * QROWS + wave * 32;
+
+    const bf16_t* Qb = Q + b * bsq + (int64_t)head * 128;
+    const bf16_t* Kb = Kp + b * bsk + (int64_t)head * 128;
+    const bf16_t* Vb = Vp + b * bsv + (int64_t)head * 128;
+
+    // ---- Q fragments: lane (lr, lh) holds Q[q0+lr][16*ks + 8*lh .. +7], ks = 0..7
+    bf16x8_t qf[8];
+    {
+        int64_t qrow = q0 + lr;
+        if (qrow > Sq - 1) qrow = Sq - 1;
+        const bf16_t* qp = Qb + qrow * ldq + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+    }
+
+    // ---- staging map: 1024 16-byte chunks per tile, two per thread per operand
+    int st_row[2], st_c[2], st_koff[2], st_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 512 * i;
+        st_row[i] = id >> 4;
+        st_c[i] = id & 15;
+        st_koff[i] = st_row[i] * 256 + ((st_c[i] ^ (st_row[i] & 15)) << 4);
+        st_voff[i] = st_row[i] * 256 + ((((st_c[i] >> 2) ^ (st_row[i] & 3)) << 6) | ((st_c[i] & 3) << 4));
+    }
+    // named registers (no arrays / lambdas: keeps the in-flight tile in VGPRs, not in a promoted alloca)
+    u32x4_t kreg0, kreg1, vreg0, vreg1;
+#define LOAD_TILE(KV0)                                                                        \
+    do {                                                                                      \
+        int64_t r0_ = (KV0) + st_row[0], r1_ = (KV0) + st_row[1];                             \
+        if (r0_ > Sk - 1) r0_ = Sk - 1;                                                       \
+        if (r1_ > Sk - 1) r1_ = Sk - 1;                                                       \
+        kreg0 = *reinterpret_cast<const u32x4_t*>(Kb + r0_ * ldk + st_c[0] * 8);              \
+        vreg0 = *reinterpret_cast<const u32x4_t*>(Vb + r0_ * ldv + st_c[0] * 8);              \
+        kreg1 = *reinterpret_cast<const u32x4_t*>(Kb + r1_ * ldk + st_c[1] * 8);              \
+        vreg1 = *reinterpret_cast<const u32x4_t*>(Vb + r1_ * ldv + st_c[1] * 8);              \
+    } while (0)
+#define WRITE_TILE(BUF)                                                                       \
+    do {                                                                                      \
+        char* ks__ = smem + (BUF) * KBYTES;                                                   \
+        char* vs__ = smem + (2 + (BUF)) * KBYTES;                                             \
+        *reinterpret_cast<u32x4_t*>(ks__ + st_koff[0]) = kreg0;                               \
+        *reinterpret_cast<u32x4_t*>(vs__ + st_voff[0]) = vreg0;                               \
+        *reinterpret_cast<u32x4_t*>(ks__ + st_koff[1]) = kreg1;                               \
+        *reinterpret_cast<u32x4_t*>(vs__ + st_voff[1]) = vreg1;                               \
+    } while (0)
+
+    // ---- LDS read offsets
+    // K (A operand of S^T): row = 32*kt2 + lr, chunk = 2*ks + lh
+    int koff[2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) koff[kt2] = (32 * kt2 + lr) * 256;
+    const int kx = lr & 15;          // swizzle key: (row & 15) == (lr & 15) for both sub-tiles
+    // V^T (A operand of O^T) via ds_read_b64_tr_b16: 16-lane group g reads a 4-key x 16-d block;
+    // lane i of the group supplies row (i>>2), columns 4*(i&3)..+3 and receives column i.
+    const int vi = lane & 15;
+    const int vq = vi >> 2, vp = vi & 3;
+    const int vdh = (lane >> 4) & 1;          // which 16-wide half of the 32-d tile
+    // byte column inside the 256-B row for d-tile dt: (32*dt + 16*vdh + 4*vp) * 2 = 64*dt + 32*vdh + 8*vp
+    // swizzled: segment (dt ^ (key&3)) * 64 + 32*vdh + 8*vp ; key&3 == vq for every block (block bases are % 4 == 0)
+    int vcol[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vcol[dt] = ((dt ^ vq) << 6) + 32 * vdh + 8 * vp;
+    const int vrow0 = (4 * lh + vq) * 256;    // + (32*kt2 + 16*s [+8]) * 256
+
+    f32x16_t acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (int)((Sk + KVT - 1) / KVT);
+    LOAD_TILE((int64_t)0);
+    WRITE_TILE(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) LOAD_TILE((int64_t)(t + 1) * KVT);
+
+        const char* ks_ = smem + buf * KBYTES;
+        const char* vs_ = smem + (2 + buf) * KBYTES;
+
+        // ---- S^T = K . Q^T
+        f32x16_t s[2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt2][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_ + koff[kt2] + (((2 * ks + lh) ^ kx) << 4));
+                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt2], 0, 0, 0);
+            }
+        }
+
+        // ---- mask keys past Sk (last tile only)
+        if ((int64_t)(t + 1) * KVT > Sk) {
+            const int64_t kbase = (int64_t)t * KVT + 4 * lh;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t key = kbase + 32 * kt2 + (r & 3) + 8 * (r >> 2);
+                    if (key >= Sk) s[kt2][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (query on the lane; partner lane^32 holds the other 32 keys)
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        const float mc = m_new * scale_log2e;
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8_t pb[2][2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);
+                psum += p[r];
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                union { bf16x8_t v; uint32_t u[4]; } cv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv.u[i] = pack_bf2(p[8 * sidx + 2 * i], p[8 * sidx + 2 * i + 1]);
+                pb[kt2][sidx] = cv.v;
+            }
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const char* vb = vs_ + vrow0 + (32 * kt2 + 16 * sidx) * 256;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x4_t lo = ds_read_tr16(vb + vcol[dt]);
+                    const bf16x4_t hi = ds_read_tr16(vb + 8 * 256 + vcol[dt]);
+                    bf16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt2][sidx], acc[dt], 0, 0, 0);
+                }
+            }
+        }
+
+        if (t + 1 < nt) WRITE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int64_t qrow = q0 + lr;
+    if (qrow < Sq) {
+        bf16_t* op = O + b * bso + qrow * ldo + (int64_t)head * 128 + 4 * lh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 o;
+                o.x = pack_bf2(acc[dt][4 * rg + 0] * inv, acc[dt][4 * rg + 1] * inv);
+                o.y = pack_bf2(acc[dt][4 * rg + 2] * inv, acc[dt][4 * rg + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rg) = o;
+            }
+    }
+}
+
+extern "C" int drn_attention_bf16(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t Sq,
+                                  int64_t Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq,
+                                  int64_t bsk, int64_t bsv, int64_t bso, float scale, void* stream) {
+    DRN_CHECK_ARG(q && k && v && o && batch > 0 && heads > 0 && Sq >= 0 && Sk > 0);
+    DRN_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
+    DRN_CHECK_ARG(bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 4 == 0);
+    DRN_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 7) == 0);
+    if (Sq == 0) return DRN_OK;
+    const int64_t nqb = (Sq + QROWS - 1) / QROWS;
+    const int64_t total = nqb * heads * batch;
+    DRN_CHECK_ARG(total < (1ll << 31));
+    const float scale_log2e = scale * 1.44269504088896340736f;
+    attention_fwd_kernel<<<dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream>>>(
+        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk,
+        bsv, bso, scale_log2e, (int)nqb, (int)total);
+    return drn_launch_status();
+}

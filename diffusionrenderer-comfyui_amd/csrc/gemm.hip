@@ -1,0 +1,182 @@
+// bf16 GEMM for the DiT linears on gfx950 MFMA:  C[M,N] = epi(A[M,K] . W[N,K]^T)
+//
+// Both operands are K-contiguous (activations [tokens, K], nn.Linear weights [out, K]), so both tiles are
+// staged by direct-to-LDS 16-byte loads (global_load_lds_dwordx4) and read back as 8-element K fragments.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2 x 2), 64x64 per wave as 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+// The MFMA is issued as D = Wfrag x Afrag so a lane ends up with 4 CONSECUTIVE output features of one token
+// (8-byte bf16 stores, and the gate / residual of the fused epilogue are read the same way).
+//
+// LDS: 2 stages x (A 16 KiB + W 16 KiB) = 64 KiB -> 2 workgroups per CU.  Rows are 128 B; the 16-byte chunk
+// index is XOR-swizzled with (row>>1)&7, which makes every ds_read_b128 lane group hit 16 distinct 16-B slots
+// of the 256-B bank row (conflict-free).  global_load_lds writes LDS lane-linearly, so the swizzle is applied
+// to the per-lane SOURCE address and again on the read (cdna guide rule 21).
+//
+// Workgroup ids are remapped so that each XCD (own L2) walks a contiguous band of tiles, 8 tile-rows deep.
+#include "drn_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)          // 16 KiB per operand per stage
+#define STAGE_BYTES (2 * TILE_BYTES)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                           bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                                           int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
+                                                           const bf16_t* R, int64_t ldr, int64_t rpb) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware, grouped tile order
+    const int tiles_m = (int)((M + BM - 1) / BM);
+    const int tiles_n = (int)(N / BN);
+    const int nwg = tiles_m * tiles_n;
+    int pid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int GROUP = 8;
+    const int width = GROUP * tiles_n;
+    const int group_id = pid / width;
+    const int first_m = group_id * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int tm = first_m + (pid % width) % gsz;
+    const int tn = (pid % width) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    // ---- staging: each wave copies 4 x 1 KiB pieces (8 rows x 128 B) of A and of W per K step
+    const bf16_t* ga[4];
+    const bf16_t* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);          // tile row 0..127
+        const int c = (lane & 7) ^ ((r >> 1) & 7);               // source chunk for LDS slot (lane&7)
+        int64_t ra = m0 + r;
+        if (ra > M - 1) ra = M - 1;                              // clamp: duplicates are never stored
+        ga[i] = A + ra * lda + c * 8;
+        gw[i] = W + (n0 + r) * ldw + c * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE_BYTES + wave * 4096;
+        char* sw = sa + TILE_BYTES;
+        const int64_t ko = (int64_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + ko), (lptr_t)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + ko), (lptr_t)(sw + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes within an operand tile), per k-substep ks: chunk = ks*4 + (lane>>4)
+    const int fr = lane & 15, fq = lane >> 4;
+    int offa[4][2], offw[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr;
+        const int rw = wn * 64 + i * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + fq;
+            offa[i][ks] = ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4);
+            offw[i][ks] = rw * 128 + ((c ^ ((rw >> 1) & 7)) << 4);
+        }
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(K / BK);
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* sa = smem + (kt & 1) * STAGE_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + offa[i][ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + offw[j][ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + fr;
+        if (m >= M) continue;
+        const int64_t b = (EPI == DRN_EPI_GATE_RES) ? m / rpb : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 16 + fq * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r]);
+            if (EPI == DRN_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            } else if (EPI == DRN_EPI_GATE_RES) {
+                const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);
+                const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);
+                const float g[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
+                const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);
+            }
+            uint2 o;
+            o.x = pack_bf2(v[0], v[1]);
+            o.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(C + m * ldc + n) = o;
+        }
+    }
+}
+
+extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                             int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
+                             int64_t ldr, int64_t rows_per_batch, void* stream) {
+    DRN_CHECK_ARG(A && W && C && M >= 0 && N > 0 && K > 0);
+    DRN_CHECK_ARG(K % BK == 0 && N % BN == 0);
+    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N);
+    DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0);
+    if (epilogue == DRN_EPI_GATE_RES)
+        DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
+    if (M == 0) return DRN_OK;
+    const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
+    DRN_CHECK_ARG(tiles < (1ll << 31));
+    dim3 grid((unsigned)tiles), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define ARGS (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, \
+             (const bf16_t*)residual, ldr, rows_per_batch
+    switch (epilogue) {
+        case DRN_EPI_NONE: gemm_bf16_kernel<DRN_EPI_NONE><<<grid, block, 0, st>>>(ARGS); break;
+        case DRN_EPI_GELU: gemm_bf16_kernel<DRN_EPI_GELU><<<grid, block, 0, st>>>(ARGS); break;
+        case DRN_EPI_GATE_RES: gemm_bf16_kernel<DRN_EPI_GATE_RES><<<grid, block, 0, st>>>(ARGS); break;
+        default: return DRN_EINVAL;
+    }
+#undef ARGS
+    return drn_launch_status();
+}

@@ -1,0 +1,253 @@
+"""HipDiT: the CleanDiffusionRendererGeneralDIT forward on hand-written gfx950 kernels.
+
+Host-side mirror of the reference operator `net(x, timesteps, latent_condition, context_index)`
+(CleanGeneralDIT.py:731-751 -> :656-718): same call signature, same state-dict names in, same
+[B,16,F,h,w] tensor out.  All arithmetic on activations runs in libdrn.so (native.py); torch is used
+for device memory, tiny host tables and (multi-GPU) the RCCL all-gather.
+
+Data layout in HBM: tokens are rows.  X [S, D] bf16 (S = F*(h/2)*(w/2) tokens in (T H W) order, the
+reference's 'B T H W D -> (T H W) B D' with B = 1), QKV [S, 3D] (q | k | v, head-major 128-wide slices),
+MLP hidden [S, 4D].  Weights are repacked once at load: q/k/v fused to [3D, D]; patch-embed K padded to a
+multiple of 64; final projection N padded to 128; all 3*L AdaLN-LoRA down/up projections stacked for
+two grouped GEMV launches per timestep.
+
+Exact shortcuts: the cross-attention has ONE key, so softmax == 1 and its output is
+to_out(to_v(context)) for every token, independent of x; its LayerNorm/modulate/q-projection are dead.
+The block reduces to x += bf16(gate * c_i) with c_i cached per context index, and that broadcast add is
+fused into the next sub-block's LayerNorm pass.
+
+Sequence parallelism (one process per GPU): rank r owns a contiguous band of latent frames; every op is
+token-local except self-attention, whose K/V rows (after RMSNorm + RoPE) are all-gathered over RCCL.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import native as N
+from .host_tables import rope_cos_sin, timestep_sinusoid
+
+
+def _pad_cols(w: torch.Tensor, mult: int) -> torch.Tensor:
+    n, k = w.shape
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return w.contiguous()
+    out = torch.zeros((n, kp), dtype=w.dtype, device=w.device)
+    out[:, :k] = w
+    return out
+
+
+def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
+    n, k = w.shape
+    npad = (n + mult - 1) // mult * mult
+    if npad == n:
+        return w.contiguous()
+    out = torch.zeros((npad, k), dtype=w.dtype, device=w.device)
+    out[:n] = w
+    return out
+
+
+class HipDiT:
+    def __init__(self, net: dict, state_dict: Dict[str, torch.Tensor], device=None, prefix: str = "net.",
+                 process_group=None):
+        self.net = dict(net)
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.D = net["model_channels"]
+        self.heads = net["num_heads"]
+        self.L = net["num_blocks"]
+        self.kinds = [k.strip().lower() for k in net["block_config"].split("-")]
+        self.pt, self.ps = net["patch_temporal"], net["patch_spatial"]
+        self.out_ch = net["out_channels"]
+        self.use_ctx = net.get("use_context_embedding", True)
+        self.ctx_dim = net["crossattn_emb_channels"]
+        self.with_mask = net.get("concat_padding_mask", True)
+        if self.D // self.heads != 128:
+            raise ValueError("HipDiT kernels are specialised for head_dim 128 (the renderer's only configuration)")
+        N.load_library()
+        self.pg = process_group
+        self._load(state_dict, prefix)
+        self._rope_cache = {}
+        self._time_cache = {}
+        self._ctx_cache = {}
+        self._ws = {}
+        self.trace = None          # tests: dict filled with per-sub-block activations "block{i}.{j}" -> [S, D]
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, sd, p):
+        dev, bf = self.device, torch.bfloat16
+
+        def g(name):
+            return sd[p + name].to(device=dev, dtype=bf)
+
+        self.w_patch = _pad_cols(g("x_embedder.proj.1.weight"), 64)
+        self.kpad = self.w_patch.shape[1]
+        self.w_t1 = g("t_embedder.1.linear_1.weight").contiguous().unsqueeze(0)
+        self.w_t2 = g("t_embedder.1.linear_2.weight").contiguous().unsqueeze(0)
+        self.w_affnorm = g("affline_norm.weight").contiguous()
+        self.seq = sd[p + "pos_embedder.seq"]
+        self.ctx_table = g("context_embedding.weight") if self.use_ctx else None
+        self.w_final = _pad_rows(g("final_layer.linear.weight"), 128)
+        self.final_cols = self.out_ch * self.ps * self.ps * self.pt
+        self.w_fa1 = g("final_layer.adaLN_modulation.1.weight").contiguous().unsqueeze(0)
+        self.w_fa2 = g("final_layer.adaLN_modulation.2.weight").contiguous().unsqueeze(0)
+
+        a1, a2 = [], []
+        self.blocks = []
+        ca_v, ca_o = [], []
+        for i in range(self.L):
+            subs = []
+            for j, kind in enumerate(self.kinds):
+                q = f"blocks.block{i}.blocks.{j}."
+                a1.append(g(q + "adaLN_modulation.1.weight"))
+                a2.append(g(q + "adaLN_modulation.2.weight"))
+                if kind == "fa":
+                    a = q + "block.attn."
+                    subs.append({"kind": "fa",
+                                 "wqkv": torch.cat([g(a + "to_q.0.weight"), g(a + "to_k.0.weight"),
+                                                    g(a + "to_v.0.weight")], 0).contiguous(),
+                                 "qn": g(a + "to_q.1.weight").contiguous(), "kn": g(a + "to_k.1.weight").contiguous(),
+                                 "wo": g(a + "to_out.0.weight").contiguous()})
+                elif kind == "ca":
+                    a = q + "block.attn."
+                    subs.append({"kind": "ca", "idx": len(ca_v)})
+                    ca_v.append(g(a + "to_v.0.weight"))
+                    ca_o.append(g(a + "to_out.0.weight"))
+                else:
+                    subs.append({"kind": "mlp", "w1": g(q + "block.layer1.weight").contiguous(),
+                                 "w2": g(q + "block.layer2.weight").contiguous()})
+            self.blocks.append(subs)
+        self.n_sites = len(a1)
+        self.r = a1[0].shape[0]
+        self.w_a1 = torch.cat(a1, 0).contiguous().unsqueeze(0)          # [1, sites*r, D]
+        self.w_a2 = torch.stack(a2, 0).contiguous()                     # [sites, 3D, r]
+        self.n_ca = len(ca_v)
+        self.w_cav = torch.stack(ca_v, 0).contiguous() if ca_v else None   # [n_ca, D, ctx]
+        self.w_cao = torch.stack(ca_o, 0).contiguous() if ca_o else None   # [n_ca, D, D]
+        # site index of every cross-attention sub-block (for its gate)
+        self.ca_sites = [i * len(self.kinds) + j for i in range(self.L) for j, k in enumerate(self.kinds) if k == "ca"]
+
+    # ------------------------------------------------------------------ per-timestep vectors (K10, K11)
+    def time_vectors(self, sigma: float):
+        """AdaLN vectors for one sigma: mod [sites, 3D] (shift|scale|gate), final [2D].  Cached per sigma."""
+        key = float(sigma)
+        hit = self._time_cache.get(key)
+        if hit is not None:
+            return hit
+        D = self.D
+        t_emb = timestep_sinusoid(key, D).to(self.device)                        # [1, D]
+        x = t_emb.view(1, 1, D)
+        h1 = N.gemv(x, self.w_t1)                                                # linear_1
+        lora = N.gemv(h1, self.w_t2, act=N.ACT_SILU)                             # linear_2(silu(.)) [1,1,3D]
+        emb = N.rmsnorm(t_emb, self.w_affnorm).view(1, 1, D)                     # affline_norm
+        a = N.gemv(emb, self.w_a1, act=N.ACT_SILU)                               # [1,1,sites*r]
+        mod = N.gemv(a.view(self.n_sites, 1, self.r), self.w_a2, add=lora)       # [sites,1,3D]
+        af = N.gemv(emb, self.w_fa1, act=N.ACT_SILU)
+        modf = N.gemv(af, self.w_fa2, add=lora[:, :, : 2 * D].contiguous())      # [1,1,2D]
+        out = (mod.view(self.n_sites, 3 * D), modf.view(2 * D))
+        if len(self._time_cache) > 256:
+            self._time_cache.clear()
+        self._time_cache[key] = out
+        return out
+
+    def context_vectors(self, context_index) -> Optional[torch.Tensor]:
+        """c_i = to_out_i(to_v_i(ctx)) for every cross-attention block: [n_ca, D].  Cached per index (F8)."""
+        if self.n_ca == 0:
+            return None
+        key = int(context_index) if self.use_ctx else -1
+        hit = self._ctx_cache.get(key)
+        if hit is not None:
+            return hit
+        if self.use_ctx:
+            ctx = self.ctx_table[key].view(1, 1, self.ctx_dim).contiguous()
+        else:
+            ctx = torch.zeros((1, 1, self.ctx_dim), dtype=torch.bfloat16, device=self.device)
+        v = N.gemv(ctx, self.w_cav)                         # [n_ca,1,D]  to_v (value norm is Identity)
+        c = N.gemv(v, self.w_cao).view(self.n_ca, self.D)   # to_out
+        self._ctx_cache[key] = c
+        return c
+
+    def rope(self, Tp, Hp, Wp):
+        key = (Tp, Hp, Wp)
+        hit = self._rope_cache.get(key)
+        if hit is None:
+            cos, sin = rope_cos_sin(Tp, Hp, Wp, 128, self.seq, torch.bfloat16)
+            hit = (cos.to(self.device), sin.to(self.device))
+            self._rope_cache[key] = hit
+        return hit
+
+    def _workspace(self, S):
+        ws = self._ws.get(S)
+        if ws is None:
+            D, dev, bf = self.D, self.device, torch.bfloat16
+            ws = {"x": torch.empty((S, D), dtype=bf, device=dev), "h": torch.empty((S, D), dtype=bf, device=dev),
+                  "qkv": torch.empty((S, 3 * D), dtype=bf, device=dev), "o": torch.empty((S, D), dtype=bf, device=dev),
+                  "u": torch.empty((S, int(D * self.net["mlp_ratio"])), dtype=bf, device=dev),
+                  "y": torch.empty((S, self.w_final.shape[0]), dtype=bf, device=dev)}
+            self._ws = {S: ws}       # keep one shape resident
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def __call__(self, x, timesteps, latent_condition, context_index=None, **_):
+        return self.forward(x, timesteps, latent_condition, context_index)
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, latent_condition, context_index=None):
+        dev, bf = self.device, torch.bfloat16
+        x = x.to(device=dev, dtype=bf).contiguous()
+        cond = latent_condition.to(device=dev, dtype=bf).contiguous()
+        B, C, F_, h, w = x.shape
+        if B != 1:
+            raise ValueError("the renderer runs batch 1 (noise is drawn with batch 1, model_diffusion_renderer.py:222)")
+        sigma = float(timesteps.flatten()[0]) if torch.is_tensor(timesteps) else float(timesteps)
+        ci = 0
+        if self.use_ctx:
+            ci = int(context_index.flatten()[0].item()) if torch.is_tensor(context_index) else int(context_index)
+        D = self.D
+        Tp, Hp, Wp = F_ // self.pt, h // self.ps, w // self.ps
+        S = Tp * Hp * Wp
+
+        mod, modf = self.time_vectors(sigma)
+        cvec = self.context_vectors(ci)
+        if cvec is not None:
+            gates = mod[self.ca_sites, 2 * D:]                 # [n_ca, D]
+            addvec = gates * cvec                              # bf16(gate * c): the whole cross-attention block
+        cos, sin = self.rope(Tp, Hp, Wp)
+        ws = self._workspace(S)
+        X, Hb, QKV, O, U, Y = ws["x"], ws["h"], ws["qkv"], ws["o"], ws["u"], ws["y"]
+
+        P = N.patchify_concat(x, cond, self.with_mask, self.pt, self.ps, self.kpad)
+        N.gemm(P, self.w_patch, out=X)
+
+        pending = None
+        site = 0
+        nk = len(self.kinds)
+        for subs in self.blocks:
+            for sb in subs:
+                m = mod[site]
+                shift, scale, gate = m[:D], m[D:2 * D], m[2 * D:]
+                if self.trace is not None and site > 0:
+                    self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = (X + pending) if pending is not None else X.clone()
+                site += 1
+                if sb["kind"] == "ca":
+                    if pending is not None:
+                        N.bcast_add(X, pending)
+                    pending = addvec[sb["idx"]]
+                    continue
+                N.ln_modulate(X, shift, scale, out=Hb, add_vec=pending)
+                pending = None
+                if sb["kind"] == "fa":
+                    N.gemm(Hb, sb["wqkv"], out=QKV)
+                    q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
+                    N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads)
+                    N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
+                    N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
+                else:
+                    N.gemm(Hb, sb["w1"], out=U, epilogue=N.EPI_GELU)
+                    N.gemm(U, sb["w2"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
+
+        if self.trace is not None:
+            self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = (X + pending) if pending is not None else X.clone()
+        N.ln_modulate(X, modf[:D], modf[D:], out=Hb, add_vec=pending)
+        N.gemm(Hb, self.w_final, out=Y)
+        return N.unpatchify(Y, 1, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)

@@ -1,0 +1,246 @@
+"""ctypes binding of libdrn.so (the C ABI of include/drn.h).
+
+PyTorch-ROCm tensors in, raw device pointers + shapes + the current HIP stream out.
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_LIB = None
+_LIB_NAME = "libdrn.so"
+
+EPI_NONE, EPI_GELU, EPI_GATE_RES = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); must match include/drn.h one-to-one
+SIGNATURES = {
+    "drn_abi_version": [],
+    "drn_error_string": [_I],
+    "drn_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _P],
+    "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
+    "drn_ln_modulate": [_P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
+    "drn_bcast_add": [_P, _P, _L, _L, _L, _P],
+    "drn_rmsnorm": [_P, _P, _P, _L, _L, _F, _P],
+    "drn_qk_norm_rope": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],
+    "drn_attention_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
+    "drn_patchify_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "drn_unpatchify": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "drn_edm_scale_input": [_P, _P, _L, _F, _P],
+    "drn_edm_step": [_P, _P, _P, _L, _F, _F, _F, _F, _P],
+    "drn_cfg_combine": [_P, _P, _P, _L, _F, _P],
+    "drn_postprocess_u8": [_P, _P, _I, _I, _I, _I, _I, _P],
+}
+_RESTYPES = {"drn_error_string": c_char_p}
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load_library():
+    """Load libdrn.so and bind every symbol declared in include/drn.h.  Raises if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
+                           "there is no CPU / eager fallback for the hot path")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if lib.drn_abi_version() != 1:
+        raise RuntimeError("libdrn.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load_library().drn_error_string(code)
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor required"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.bfloat16, f"bf16 tensor required, got {t.dtype}"
+
+
+# ----------------------------------------------------------------------------------------------- wrappers
+
+def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_batch=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T).  a/w/out may be row-strided 2-D views (last dim contiguous)."""
+    _bf16(a, w, out, gate, residual)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    ldr = residual.stride(0) if residual is not None else 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+    _check(load_library().drn_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+                                        epilogue, _ptr(gate), _ptr(residual), ldr,
+                                        rows_per_batch if rows_per_batch else max(M, 1), _stream()), "drn_gemm_bf16")
+    return out
+
+
+def gemv(x, w, out=None, add=None, mul=None, act=ACT_NONE):
+    """Grouped batch-1 GEMV.  x: [G|1, B, K]; w: [G, N, K]; out/add/mul: [G, B, N] (add/mul may have G == 1)."""
+    _bf16(x, w, out, add, mul)
+    G, N, K = w.shape
+    assert x.dim() == 3 and x.shape[2] == K and x.is_contiguous() and w.is_contiguous()
+    B = x.shape[1]
+    if out is None:
+        out = torch.empty((G, B, N), dtype=torch.bfloat16, device=x.device)
+    assert out.shape == (G, B, N) and out.is_contiguous()
+
+    def gs(t, inner):
+        if t is None:
+            return 0, 0
+        assert t.is_contiguous() and t.dim() == 3 and t.shape[1] == B and t.shape[2] == inner
+        return (0 if t.shape[0] == 1 else B * inner), inner
+
+    xg, xb = gs(x, K)
+    ag, ab = gs(add, N)
+    mg, mb = gs(mul, N)
+    _check(load_library().drn_gemv_bf16(_ptr(x), _ptr(w), _ptr(out), N, K, G, B, xg, xb, N * K, B * N, N,
+                                        _ptr(add), ag, ab, _ptr(mul), mg, mb, act, _stream()), "drn_gemv_bf16")
+    return out
+
+
+def ln_modulate(x, shift, scale, out=None, add_vec=None, rows_per_batch=None, eps=1e-6):
+    """out = bf16(bf16(LN(x) * bf16(1+scale)) + shift); if add_vec: x <- bf16(x + add_vec) in place first."""
+    _bf16(x, shift, scale, out, add_vec)
+    rows, D = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load_library().drn_ln_modulate(_ptr(x), _ptr(add_vec), _ptr(shift), _ptr(scale), _ptr(out), rows, D,
+                                          rows_per_batch if rows_per_batch else max(rows, 1), eps, _stream()),
+           "drn_ln_modulate")
+    return out
+
+
+def bcast_add(x, vec, rows_per_batch=None):
+    _bf16(x, vec)
+    rows, D = x.shape
+    assert x.is_contiguous()
+    _check(load_library().drn_bcast_add(_ptr(x), _ptr(vec), rows, D, rows_per_batch if rows_per_batch else max(rows, 1),
+                                        _stream()), "drn_bcast_add")
+    return x
+
+
+def rmsnorm(x, w, eps=1e-6):
+    _bf16(x, w)
+    rows, D = x.shape
+    out = torch.empty_like(x)
+    _check(load_library().drn_rmsnorm(_ptr(x), _ptr(w), _ptr(out), rows, D, eps, _stream()), "drn_rmsnorm")
+    return out
+
+
+def qk_norm_rope(q, k, wq, wk, cos, sin, heads, tokens_per_batch=None, pos_offset=0, eps=1e-6):
+    """In place on q,k: [tokens, heads*128] views (row stride = q.stride(0))."""
+    _bf16(q, k, wq, wk, cos, sin)
+    tokens = q.shape[0]
+    assert q.shape[1] == heads * 128 and k.shape == q.shape and q.stride(1) == 1 and k.stride(1) == 1
+    assert q.stride(0) == k.stride(0)
+    _check(load_library().drn_qk_norm_rope(_ptr(q), _ptr(k), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin), tokens, heads,
+                                           q.stride(0), tokens_per_batch if tokens_per_batch else max(tokens, 1),
+                                           pos_offset, eps, _stream()), "drn_qk_norm_rope")
+
+
+def attention(q, k, v, out=None, heads=None, scale=None):
+    """q: [B, Sq, H*128], k/v: [B, Sk, H*128] (token-strided views allowed) -> out [B, Sq, H*128]."""
+    _bf16(q, k, v, out)
+    B, Sq, HD = q.shape
+    Sk = k.shape[1]
+    H = heads if heads else HD // 128
+    assert HD == H * 128 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        out = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = 1.0 / (128 ** 0.5)
+    _check(load_library().drn_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
+                                             q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                             q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+           "drn_attention_bf16")
+    return out
+
+
+def patchify_concat(x, cond, with_mask, pt, ps, ldo):
+    _bf16(x, cond)
+    B, Cx, T, H, W = x.shape
+    Cc = cond.shape[1] if cond is not None else 0
+    assert x.is_contiguous() and (cond is None or cond.is_contiguous())
+    rows = B * (T // pt) * (H // ps) * (W // ps)
+    out = torch.empty((rows, ldo), dtype=torch.bfloat16, device=x.device)
+    _check(load_library().drn_patchify_concat(_ptr(x), _ptr(cond), _ptr(out), B, Cx, Cc, 1 if with_mask else 0, T, H, W,
+                                              pt, ps, ldo, _stream()), "drn_patchify_concat")
+    return out
+
+
+def unpatchify(y, B, C, Tp, Hp, Wp, pt, ps):
+    _bf16(y)
+    assert y.stride(1) == 1
+    out = torch.empty((B, C, Tp * pt, Hp * ps, Wp * ps), dtype=torch.bfloat16, device=y.device)
+    _check(load_library().drn_unpatchify(_ptr(y), y.stride(0), _ptr(out), B, C, Tp, Hp, Wp, pt, ps, _stream()),
+           "drn_unpatchify")
+    return out
+
+
+def edm_scale_input(x, c_in: float):
+    _bf16(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _check(load_library().drn_edm_scale_input(_ptr(x), _ptr(out), x.numel(), c_in, _stream()), "drn_edm_scale_input")
+    return out
+
+
+def edm_step(model_out, sample, c_skip: float, c_out: float, sigma: float, dt: float):
+    _bf16(model_out, sample)
+    assert model_out.is_contiguous() and sample.is_contiguous() and model_out.numel() == sample.numel()
+    out = torch.empty_like(sample)
+    _check(load_library().drn_edm_step(_ptr(model_out), _ptr(sample), _ptr(out), sample.numel(), c_skip, c_out, sigma, dt,
+                                       _stream()), "drn_edm_step")
+    return out
+
+
+def cfg_combine(cond, uncond, guidance: float):
+    _bf16(cond, uncond)
+    assert cond.is_contiguous() and uncond.is_contiguous()
+    out = torch.empty_like(cond)
+    _check(load_library().drn_cfg_combine(_ptr(cond), _ptr(uncond), _ptr(out), cond.numel(), guidance, _stream()),
+           "drn_cfg_combine")
+    return out
+
+
+def postprocess_u8(video, normalize_normal: bool):
+    """video [B,3,T,H,W] bf16 -> uint8 [B,T,H,W,3]."""
+    _bf16(video)
+    B, C, T, H, W = video.shape
+    assert C == 3 and video.is_contiguous()
+    out = torch.empty((B, T, H, W, 3), dtype=torch.uint8, device=video.device)
+    _check(load_library().drn_postprocess_u8(_ptr(video), _ptr(out), B, T, H, W, 1 if normalize_normal else 0, _stream()),
+           "drn_postprocess_u8")
+    return out

@@ -1,0 +1,124 @@
+/* drn.h - C ABI of libdrn.so: the MI355X (gfx950) kernels behind the DiffusionRenderer
+ * denoising hot path (CleanGeneralDIT forward + EDM sampler steps + Cosmos CV8x8x8 tokenizer).
+ *
+ * The reference (eggsbenedicto/DiffusionRenderer-ComfyUI) is pure Python/torch and has no FFI;
+ * each entry point below names the reference code (file:line under /root/reference) whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (e.g. torch tensor.data_ptr());
+ *     the library allocates nothing and keeps no pointer after a call returns;
+ *   - bf16 tensors are raw 16-bit words, row-major, innermost dimension contiguous;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); kernels are only
+ *     enqueued, never synchronised;
+ *   - return value: DRN_OK (0), DRN_EINVAL (-1) for a shape/alignment the kernels do not
+ *     support (nothing was launched), or a positive hipError_t from the launch;
+ *   - not thread-safe per stream; one host thread per process/GPU (ComfyUI runs nodes serially).
+ */
+#ifndef DRN_H
+#define DRN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRN_OK 0
+#define DRN_EINVAL (-1)
+
+#define DRN_ABI_VERSION 1
+
+/* GEMM epilogues */
+#define DRN_EPI_NONE 0      /* C = bf16(acc)                                            nn.Linear */
+#define DRN_EPI_GELU 1      /* C = bf16(gelu_erf(bf16(acc)))                            CleanGeneralDIT.py:454-457 */
+#define DRN_EPI_GATE_RES 2  /* C = bf16(R + bf16(gate * bf16(acc)))                     CleanGeneralDIT.py:517 */
+
+/* GEMV input activation */
+#define DRN_ACT_NONE 0
+#define DRN_ACT_SILU 1      /* x <- bf16(silu(x)) before the product                     CleanGeneralDIT.py:342,485 */
+
+int drn_abi_version(void);
+const char* drn_error_string(int code);
+
+/* ---- token-parallel GEMM: C[M,N] = epi(A[M,K] . W[N,K]^T), bf16 in, fp32 MFMA accumulate, bf16 out.
+ * Replaces every nn.Linear of the DiT blocks (CleanGeneralDIT.py:273-276 q/k/v, :254-257 to_out,
+ * :445-447 MLP, :386/:417 patch embed, :555/:590 final linear) plus the GELU (:446) and the gated
+ * residual (:517) that follow them.
+ * Requirements: K % 64 == 0, N % 128 == 0, lda/ldw/ldc/ldr % 8 == 0, 16-byte aligned bases.
+ * gate: [batches, N] bf16 (row r uses batch r / rows_per_batch); residual R: [M, ldr] bf16 (may alias C). */
+int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
+                  int64_t lda, int64_t ldw, int64_t ldc, int epilogue,
+                  const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
+                  void* stream);
+
+/* ---- weight-streaming GEMV family (batch-1 vectors: timestep MLP, AdaLN-LoRA, the 1-key cross-attention).
+ * For g in [0,groups), b in [0,batch): y[g,b,:] = epi(W[g] . act(x[g,b,:]))   W[g]: [N,K] bf16
+ *   y = bf16(acc); if add: y = bf16(y + add[g,b,n]); if mul: y = bf16(mul[g,b,n] * y)
+ * Replaces CleanGeneralDIT.py:358-360 (timestep MLP), :483-488/:500-505 (AdaLN-LoRA), :558-562/:572 (final AdaLN),
+ * and to_v/to_out of the cross-attention whose single key makes softmax == 1.
+ * Strides are in elements; a stride of 0 shares the operand between groups.  K % 8 == 0. */
+int drn_gemv_bf16(const void* x, const void* W, void* y, int64_t N, int64_t K,
+                  int groups, int batch,
+                  int64_t x_gstride, int64_t x_bstride, int64_t w_gstride,
+                  int64_t y_gstride, int64_t y_bstride,
+                  const void* add, int64_t add_gstride, int64_t add_bstride,
+                  const void* mul, int64_t mul_gstride, int64_t mul_bstride,
+                  int act, void* stream);
+
+/* ---- LayerNorm(eps, no affine) + AdaLN modulate, one pass: h = bf16(bf16(LN(x) * bf16(1+scale)) + shift)
+ * with the reference's rounding points (CleanGeneralDIT.py:7-11, :481, :506; final layer :587).
+ * If add_vec != NULL the row is first updated in place, x <- bf16(x + add_vec[batch]) (the broadcast
+ * cross-attention residual, :517 with F8), and LN runs on the updated row.
+ * x,h: [rows, D] bf16; shift/scale/add_vec: [batches, D] bf16; batch = row / rows_per_batch. D % 8 == 0, D <= 8192. */
+int drn_ln_modulate(void* x, const void* add_vec, const void* shift, const void* scale, void* h,
+                    int64_t rows, int64_t D, int64_t rows_per_batch, float eps, void* stream);
+
+/* ---- x[rows,D] <- bf16(x + vec[batch,:]) (stand-alone broadcast residual; same arithmetic as above) */
+int drn_bcast_add(void* x, const void* vec, int64_t rows, int64_t D, int64_t rows_per_batch, void* stream);
+
+/* ---- RMSNorm over the last dim, fp32 internal: y = bf16(x * rsqrt(mean(x^2)+eps) * w)   CleanGeneralDIT.py:14-33 */
+int drn_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t D, float eps, void* stream);
+
+/* ---- per-head RMSNorm(q), RMSNorm(k) + 3-D RoPE, in place (CleanGeneralDIT.py:288-295, :45-84).
+ * q,k: [tokens, heads, 128] views with row stride `ld` elements (e.g. the fused QKV GEMM output);
+ * wq,wk: [128] bf16; cos,sin: [tokens_per_batch, 128] bf16 host-built tables, NULL = no RoPE.
+ * rotate_half pairs lane i with i+64.  token t uses table row pos_offset + (t % tokens_per_batch). head_dim must be 128. */
+int drn_qk_norm_rope(void* q, void* k, const void* wq, const void* wk, const void* cos, const void* sin,
+                     int64_t tokens, int heads, int64_t ld, int64_t tokens_per_batch, int64_t pos_offset,
+                     float eps, void* stream);
+
+/* ---- non-causal scaled-dot-product attention, head_dim 128, online softmax in fp32, bf16 P for the PV MFMA.
+ * Replaces F.scaled_dot_product_attention + the sbhd<->bhsd permutes + the F1 head flatten
+ * (CleanGeneralDIT.py:181-203, :299-304).  q,o: [batch, Sq, heads, 128]; k,v: [batch, Sk, heads, 128] given by
+ * element strides (token stride ld*, batch stride bs*; head h at offset h*128). */
+int drn_attention_bf16(const void* q, const void* k, const void* v, void* o,
+                       int batch, int heads, int64_t Sq, int64_t Sk,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                       int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                       float scale, void* stream);
+
+/* ---- patchify + channel concat: out[b*T*H*W + (t,h,w), (c r m n)] gathered from x | cond | ones-mask
+ * (CleanGeneralDIT.py:669-675, :409-414).  x: [B,Cx,Tl,Hl,Wl], cond: [B,Cc,Tl,Hl,Wl] bf16; with_mask appends the
+ * all-ones channel; columns [C*pt*ps*ps, ldo) are zero-filled (K padding for the GEMM).  Bit-exact index op. */
+int drn_patchify_concat(const void* x, const void* cond, void* out, int B, int Cx, int Cc, int with_mask,
+                        int Tl, int Hl, int Wl, int pt, int ps, int64_t ldo, void* stream);
+
+/* ---- unpatchify: y[(B T)(H W), (ph pw pt C)] -> out[B, C, T*pt, H*ps, W*ps]  (CleanGeneralDIT.py:709-716). Bit-exact. */
+int drn_unpatchify(const void* y, int64_t ldy, void* out, int B, int C, int Tp, int Hp, int Wp, int pt, int ps,
+                   void* stream);
+
+/* ---- EDM Euler sampler, fp32 math on bf16 latents (model_diffusion_renderer.py:30-82, :232) */
+int drn_edm_scale_input(const void* x, void* out, int64_t n, float c_in, void* stream);
+int drn_edm_step(const void* model_out, const void* sample, void* out, int64_t n,
+                 float c_skip, float c_out, float sigma, float dt, void* stream);
+int drn_cfg_combine(const void* cond, const void* uncond, void* out, int64_t n, float guidance, void* stream);
+
+/* ---- pipeline post-process (diffusion_renderer_pipeline.py:299-318): optional normal re-normalisation blend,
+ * (1+v).clamp(0,2)/2, permute to (B,T,H,W,C), *255, truncating uint8 cast.  video: [B,3,T,H,W] bf16. Bit-exact. */
+int drn_postprocess_u8(const void* video, void* out_u8, int B, int T, int H, int W, int normalize_normal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRN_H */

@@ -1,0 +1,291 @@
+"""Per-kernel parity of libdrn.so (through the C ABI) against the CPU oracle / fp32 torch references.
+
+Bit-exact where the op is an index map or a restatement of unfused fp32 ops (patchify, unpatchify, EDM step,
+CFG, uint8 post-process); for reductions / MFMA products the result must equal the reference rounded to bf16 up to
+accumulation-order flips: <= 1 bf16 ulp everywhere, and rel-L2 against the fp32 value <= the stated tolerance.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import dit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def ulp_diff_ok(out, ref, max_ulp=1, frac_exact=0.98):
+    """out, ref bf16: every element within max_ulp bf16 ulps of ref, and most exactly equal."""
+    o, r = out.float(), ref.float()
+    ulp = torch.maximum(r.abs(), o.abs()) * 2.0 ** -7 + 1e-30
+    bad = ((o - r).abs() > max_ulp * ulp).sum().item()
+    exact = (out == ref).float().mean().item()
+    return bad == 0 and exact >= frac_exact, f"bad={bad} exact={exact:.5f}"
+
+
+def rnd(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (1000, 256, 256), (2304, 1024, 512), (77, 128, 128)])
+def test_gemm_plain(pkg, gpu, M, N, K):
+    a, w = rnd((M, K), gpu, seed=1), rnd((N, K), gpu, 0.1, seed=2)
+    out = pkg.native.gemm(a, w)
+    ref32 = a.float() @ w.float().t()
+    ok, msg = ulp_diff_ok(out, ref32.to(BF))
+    assert ok, msg
+    assert rel_l2(out, ref32) < 3e-3          # bf16 output rounding alone is ~1.1e-3 rms
+
+
+def test_gemm_identity_asymmetric(pkg, gpu):
+    """A = I with an asymmetric W catches a transposed fragment or C map (cdna guide, section 3)."""
+    K = N = 128
+    a = torch.eye(128, K, dtype=BF, device=gpu)
+    w = (torch.arange(N * K, device=gpu).reshape(N, K) % 251).to(BF)
+    out = pkg.native.gemm(a, w)
+    assert torch.equal(out, w.t().contiguous())
+
+
+def test_gemm_strided_views_and_tail(pkg, gpu):
+    M, D = 300, 256
+    big = rnd((M, 3 * D), gpu, seed=3)
+    w = rnd((128, D), gpu, 0.1, seed=4)
+    out = pkg.native.gemm(big[:, D:2 * D], w)
+    ref = (big[:, D:2 * D].float() @ w.float().t()).to(BF)
+    ok, msg = ulp_diff_ok(out, ref)
+    assert ok, msg
+
+
+def test_gemm_gelu_epilogue(pkg, gpu):
+    M, N, K = 512, 256, 256
+    a, w = rnd((M, K), gpu, seed=5), rnd((N, K), gpu, 0.1, seed=6)
+    out = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GELU)
+    lin = (a.float() @ w.float().t()).to(BF)
+    ref = F.gelu(lin.cpu()).to(gpu)            # torch CPU bf16 erf-GELU: what the reference runs
+    ok, msg = ulp_diff_ok(out, ref, max_ulp=2, frac_exact=0.97)
+    assert ok, msg
+
+
+def test_gemm_gate_residual_epilogue_inplace(pkg, gpu):
+    M, N, K = 640, 256, 512
+    a, w = rnd((M, K), gpu, seed=7), rnd((N, K), gpu, 0.05, seed=8)
+    x = rnd((M, N), gpu, seed=9)
+    gate = rnd((1, N), gpu, 0.5, seed=10)
+    lin = (a.float() @ w.float().t()).to(BF)
+    ref = x + gate * lin                        # bf16 torch ops: two roundings, as CleanGeneralDIT.py:517
+    xs = x.clone()
+    pkg.native.gemm(a, w, out=xs, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=xs)
+    ok, msg = ulp_diff_ok(xs, ref, max_ulp=2, frac_exact=0.97)
+    assert ok, msg
+
+
+def test_gemm_rejects_bad_shapes(pkg, gpu):
+    a, w = rnd((64, 100), gpu), rnd((128, 100), gpu)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        pkg.native.gemm(a, w)
+
+
+# ------------------------------------------------------------------------------------------------ GEMV
+def test_gemv_grouped_silu_add_mul(pkg, gpu):
+    G, B, Nn, K = 5, 1, 384, 256
+    x = rnd((G, B, K), gpu, seed=11)
+    w = rnd((G, Nn, K), gpu, 0.1, seed=12)
+    add = rnd((1, B, Nn), gpu, seed=13)
+    mul = rnd((G, B, Nn), gpu, seed=14)
+    out = pkg.native.gemv(x, w, add=add, mul=mul, act=pkg.native.ACT_SILU)
+    xa = F.silu(x.cpu()).float()                                   # bf16 rounding of silu as torch CPU does
+    lin = torch.einsum("gbk,gnk->gbn", xa, w.cpu().float()).to(BF)
+    ref = (mul.cpu() * (lin + add.cpu())).to(gpu)
+    ok, msg = ulp_diff_ok(out, ref, max_ulp=2, frac_exact=0.95)
+    assert ok, msg
+
+
+def test_gemv_shared_input(pkg, gpu):
+    x = rnd((1, 1, 4096), gpu, seed=15)
+    w = rnd((1, 1024, 4096), gpu, 0.02, seed=16)
+    out = pkg.native.gemv(x, w)
+    ref = (x.float().view(1, 4096) @ w.float().view(1024, 4096).t()).to(BF).view(1, 1, 1024)
+    ok, msg = ulp_diff_ok(out, ref)
+    assert ok, msg
+
+
+# ------------------------------------------------------------------------------------------------ norms / RoPE
+@pytest.mark.parametrize("rows,D", [(37, 256), (64, 512), (300, 4096)])
+def test_ln_modulate_matches_oracle(pkg, gpu, rows, D):
+    x = rnd((rows, D), gpu, 2.0, seed=17)
+    shift, scale = rnd((1, D), gpu, 0.7, seed=18), rnd((1, D), gpu, 0.7, seed=19)
+    out = pkg.native.ln_modulate(x.clone(), shift, scale)
+    xc = x.cpu().unsqueeze(1)
+    ref = O.modulate(F.layer_norm(xc, (D,), eps=1e-6), shift.cpu(), scale.cpu()).squeeze(1)
+    ok, msg = ulp_diff_ok(out.cpu(), ref, max_ulp=1, frac_exact=0.995)
+    assert ok, msg
+
+
+def test_ln_modulate_with_broadcast_add(pkg, gpu):
+    rows, D = 129, 512
+    x = rnd((rows, D), gpu, 2.0, seed=20)
+    add = rnd((1, D), gpu, 0.5, seed=21)
+    shift, scale = rnd((1, D), gpu, 0.7, seed=22), rnd((1, D), gpu, 0.7, seed=23)
+    xs = x.clone()
+    out = pkg.native.ln_modulate(xs, shift, scale, add_vec=add)
+    x2 = x.cpu() + add.cpu()
+    assert torch.equal(xs.cpu(), x2)
+    ref = O.modulate(F.layer_norm(x2.unsqueeze(1), (D,), eps=1e-6), shift.cpu(), scale.cpu()).squeeze(1)
+    ok, msg = ulp_diff_ok(out.cpu(), ref, max_ulp=1, frac_exact=0.995)
+    assert ok, msg
+    x3 = x.clone()
+    pkg.native.bcast_add(x3, add)
+    assert torch.equal(x3.cpu(), x2)
+
+
+def test_rmsnorm_matches_oracle(pkg, gpu):
+    x, w = rnd((3, 4096), gpu, seed=24), rnd((4096,), gpu, seed=25)
+    out = pkg.native.rmsnorm(x, w)
+    ok, msg = ulp_diff_ok(out.cpu(), O.rms_norm(x.cpu(), w.cpu()), max_ulp=1, frac_exact=0.995)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("heads,T,H,W", [(2, 2, 8, 8), (4, 1, 6, 10), (32, 1, 4, 4)])
+def test_qk_norm_rope_matches_oracle(pkg, gpu, heads, T, H, W):
+    S, D = T * H * W, heads * 128
+    qkv = rnd((S, 3 * D), gpu, 1.5, seed=26)
+    wq, wk = 1 + 0.1 * rnd((128,), gpu, seed=27), 1 + 0.1 * rnd((128,), gpu, seed=28)
+    seq = torch.arange(512, dtype=torch.float32).to(BF)
+    cos, sin = pkg.host_tables.rope_cos_sin(T, H, W, 128, seq)
+    ang = O.rope_angles(T, H, W, 128, seq, BF)
+    oc, os_ = O.rope_cos_sin(ang, BF)
+    assert torch.equal(cos, oc) and torch.equal(sin, os_)           # host tables are bit-exact restatements
+    ref_in = qkv.cpu()
+    work = qkv.clone()
+    pkg.native.qk_norm_rope(work[:, :D], work[:, D:2 * D], wq, wk, cos.to(gpu), sin.to(gpu), heads)
+    for idx, wn in ((0, wq), (1, wk)):
+        t = ref_in[:, idx * D:(idx + 1) * D].reshape(S, 1, heads, 128)
+        ref = O.apply_rope(O.rms_norm(t, wn.cpu()), oc, os_).reshape(S, D)
+        ok, msg = ulp_diff_ok(work[:, idx * D:(idx + 1) * D].cpu(), ref, max_ulp=1, frac_exact=0.99)
+        assert ok, msg
+    assert torch.equal(work[:, 2 * D:], qkv[:, 2 * D:])              # v untouched
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, heads):
+    B, Sq, HD = q.shape
+    qh = q.float().view(B, Sq, heads, 128).transpose(1, 2)
+    kh = k.float().view(B, -1, heads, 128).transpose(1, 2)
+    vh = v.float().view(B, -1, heads, 128).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(128)
+    o = torch.softmax(s, -1) @ vh
+    return o.transpose(1, 2).reshape(B, Sq, HD)
+
+
+@pytest.mark.parametrize("heads,Sq,Sk", [(2, 256, 256), (2, 128, 128), (4, 300, 300), (1, 513, 77), (32, 256, 1024)])
+def test_attention_matches_fp32(pkg, gpu, heads, Sq, Sk):
+    q = rnd((1, Sq, heads * 128), gpu, seed=29)
+    k = rnd((1, Sk, heads * 128), gpu, seed=30)
+    v = rnd((1, Sk, heads * 128), gpu, seed=31)
+    out = pkg.native.attention(q, k, v, heads=heads)
+    ref = _attn_ref(q, k, v, heads)
+    assert rel_l2(out, ref) < 4e-3
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+def test_attention_strided_qkv_buffer(pkg, gpu):
+    heads, S = 2, 320
+    D = heads * 128
+    qkv = rnd((S, 3 * D), gpu, seed=32)
+    q, k, v = (qkv[:, i * D:(i + 1) * D].unsqueeze(0) for i in range(3))
+    out = pkg.native.attention(q, k, v, heads=heads)
+    assert rel_l2(out, _attn_ref(q, k, v, heads)) < 4e-3
+
+
+def test_attention_online_softmax_rescale_spike(pkg, gpu):
+    """Force the running max to jump at a late KV tile (guide rule 26): one key strongly aligned with one query."""
+    heads, S = 1, 512
+    q = rnd((1, S, 128), gpu, 0.3, seed=33)
+    k = rnd((1, S, 128), gpu, 0.3, seed=34)
+    v = rnd((1, S, 128), gpu, 1.0, seed=35)
+    k[0, 400] = (q[0, 17].float() * 40).to(BF)       # score jumps by a large margin in tile 6
+    k[0, 130] = (q[0, 200].float() * 25).to(BF)
+    out = pkg.native.attention(q, k, v, heads=heads)
+    ref = _attn_ref(q, k, v, heads)
+    assert rel_l2(out, ref) < 4e-3
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+def test_attention_large_scores_no_overflow(pkg, gpu):
+    heads, S = 2, 256
+    q = rnd((1, S, heads * 128), gpu, 6.0, seed=36)
+    k = rnd((1, S, heads * 128), gpu, 6.0, seed=37)
+    v = rnd((1, S, heads * 128), gpu, seed=38)
+    out = pkg.native.attention(q, k, v, heads=heads)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, _attn_ref(q, k, v, heads)) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------ index ops (bit-exact)
+@pytest.mark.parametrize("Cc,T,H,W", [(16, 2, 16, 16), (136, 1, 8, 12)])
+def test_patchify_concat_bit_exact(pkg, gpu, Cc, T, H, W):
+    x = rnd((1, 16, T, H, W), gpu, seed=39)
+    cond = rnd((1, Cc, T, H, W), gpu, seed=40)
+    C = 16 + Cc + 1
+    ldo = (C * 4 + 63) // 64 * 64
+    out = pkg.native.patchify_concat(x, cond, True, 1, 2, ldo).cpu()
+    xc = torch.cat([x.cpu(), cond.cpu(), torch.ones(1, 1, T, H, W, dtype=BF)], 1)
+    ref = O.patchify(xc, 1, 2).reshape(-1, C * 4)
+    assert torch.equal(out[:, : C * 4], ref)
+    assert (out[:, C * 4:] == 0).all()
+
+
+def test_unpatchify_bit_exact(pkg, gpu):
+    Tp, Hp, Wp = 2, 5, 7
+    y = rnd((Tp * Hp * Wp, 128), gpu, seed=41)
+    out = pkg.native.unpatchify(y, 1, 16, Tp, Hp, Wp, 1, 2).cpu()
+    ref = O.unpatchify(y[:, :64].cpu().reshape(Tp, Hp * Wp, 64), 1, Tp, Hp, Wp, 1, 2, 16)
+    assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------------------------------------ sampler / post-process (bit-exact)
+def test_edm_kernels_bit_exact(pkg, gpu):
+    x = rnd((1, 16, 2, 9, 11), gpu, 40.0, seed=42)
+    mo = rnd((1, 16, 2, 9, 11), gpu, 1.0, seed=43)
+    sig = O.edm_sigmas(6)
+    for i in range(6):
+        s, sn = sig[i], sig[i + 1]
+        c_in = (1 / torch.sqrt(s ** 2 + 0.5 ** 2)).item()
+        assert torch.equal(pkg.native.edm_scale_input(x, c_in).cpu(), O.edm_scale_input(x.cpu(), s))
+        c_skip = (0.5 ** 2 / (s ** 2 + 0.5 ** 2)).item()
+        c_out = ((s * 0.5) / torch.sqrt(s ** 2 + 0.5 ** 2)).item()
+        got = pkg.native.edm_step(mo, x, c_skip, c_out, s.item(), (sn - s).item()).cpu()
+        assert torch.equal(got, O.edm_step(mo.cpu(), s, sn, x.cpu())), f"step {i}"
+
+
+def test_cfg_combine_bit_exact(pkg, gpu):
+    c, u = rnd((4096,), gpu, seed=44), rnd((4096,), gpu, seed=45)
+    for g in (2.0, 0.7):
+        ref = c.cpu() + g * (c.cpu() - u.cpu())
+        assert torch.equal(pkg.native.cfg_combine(c, u, g).cpu(), ref)
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_postprocess_u8_bit_exact(pkg, gpu, normalize):
+    v = rnd((1, 3, 3, 20, 24), gpu, 0.8, seed=46)
+    v[0, :, 0, 0, :4] = 0                       # zero-norm pixels (clamp(min=1e-12) path)
+    v[0, :, 0, 1, :8] *= 0.3                    # norms inside the 0.2..0.4 blend band
+    got = pkg.native.postprocess_u8(v, normalize).cpu()
+    ref = O.postprocess(v.cpu(), normalize)
+    assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
+
+
+def test_postprocess_all_bf16_values(pkg, gpu):
+    """Every bf16 value in [-1.5, 1.5] through the uint8 conversion."""
+    bits = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(BF)
+    vals = bits[torch.isfinite(bits.float()) & (bits.float().abs() <= 1.5)]
+    n = vals.numel() // 3 * 3
+    v = vals[:n].reshape(1, 3, 1, 1, n // 3).contiguous()
+    got = pkg.native.postprocess_u8(v.to(gpu), False).cpu()
+    assert torch.equal(got, O.postprocess(v, False))
