@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps/s of the DiffusionRenderer inverse pass on a 57 f x 576 x 1024 clip.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N=1 default)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one EDM Euler iteration of one G-buffer pass at guidance 0 (the node default, nodes.py:139): scale the
+latent, ONE 7.2 B-parameter DiT forward over S = 18432 tokens, Euler update.  Inputs (noise latent, condition latent,
+random-init weights of the real architecture) are synthetic and resident in HBM before the timed region.
+With N > 1 the token rows of the ONE clip are sharded over the ranks (strong scaling): K/V all-gather over RCCL per
+self-attention block, everything else token-local.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus
+  roofline     - dominant kernel (by time) of the timed region, HIP-event timed on the launch stream
+  cpu_baseline - the CPU oracle (oracle/dit_oracle.py, a bit-exact restatement of the reference's CPU path) timed on
+                 this host's cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def dit_flops(S, D=4096, L=28, faithful=True):
+    """Algorithmic FLOPs of one DiT forward: linear 28 D^2 L per token (+ attention 4 S D L).
+    `faithful` counts the reference's dead cross-attention q/out projections; executed = without them (F8)."""
+    lin = (28 if faithful else 24) * D * D * L * S
+    att = 4.0 * S * S * D * L
+    return lin + att
+
+
+def cpu_baseline(pkg, S_full, budget_s=40.0):
+    """Time the CPU oracle on one full-width block (FA+CA+MLP) and extrapolate x28 (a whole cfg-3 step is minutes)."""
+    from oracle import dit_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    cores = torch.get_num_threads()
+    net = dict(pkg.diffusion_renderer_config.get_inverse_renderer_config()["net"], num_blocks=1)
+    sd = pkg.synthetic_weights.synth_state_dict(net, torch.bfloat16)
+    orc = O.DitOracle(sd, net, dtype=torch.bfloat16)
+
+    def run(F_, h, w):
+        x = pkg.synthetic_weights.synth_tensor("cpu.x", (1, 16, F_, h, w), torch.float32, scale=2.0).to(torch.bfloat16)
+        c = pkg.synthetic_weights.synth_tensor("cpu.c", (1, 16, F_, h, w), torch.float32, scale=1.0).to(torch.bfloat16)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc.forward(x, torch.tensor(2.0), c, torch.full((1, 1), 3, dtype=torch.long))
+        return time.perf_counter() - t0
+
+    run(1, 16, 16)                                   # warm the thread pool / oneDNN primitives
+    t_small = run(1, 128, 64)                        # S = 2048
+    f_small, f_full = dit_flops(2048, L=1), dit_flops(S_full, L=1)
+    est = t_small * f_full / f_small
+    if est <= budget_s:
+        t_blk = run(8, 72, 128) if S_full == 18432 else run(1, 2 * int((S_full) ** 0.5), 2 * int((S_full) ** 0.5))
+        sample = f"1 of 28 blocks (+embed/final) at S={S_full}, measured {t_blk:.1f}s, x28"
+    else:
+        t_blk = est
+        sample = (f"1 of 28 blocks at S=2048 measured {t_small:.2f}s, scaled by the FLOP ratio to S={S_full} "
+                  f"({est:.0f}s/block est.), x28")
+    return {"value": 1.0 / (28.0 * t_blk), "unit": "steps/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=57)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--blocks", type=int, default=28, help="debug only; the headline number needs 28")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    pkg = load_package()
+    N = pkg.native
+    N.load_library()
+    cfg = pkg.diffusion_renderer_config.get_inverse_renderer_config(args.height, args.width, args.frames)
+    net = dict(cfg["net"], num_blocks=args.blocks)
+    F_, h, w = (args.frames - 1) // 8 + 1, args.height // 8, args.width // 8
+    S = F_ * (h // 2) * (w // 2)
+
+    sw = pkg.synthetic_weights
+    sd = sw.synth_state_dict(net, torch.bfloat16, device=dev)
+    model = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(dict(cfg, net=net), device=dev, process_group=pg)
+    model.load_state_dict(sd, strict=True)
+    del sd
+    torch.cuda.empty_cache()
+
+    total = args.steps + args.warmup
+    model.scheduler.set_timesteps(max(total, 2))
+    sig = model.scheduler.sigmas
+    xt = (sw.synth_tensor("bench.noise", (1, 16, F_, h, w), torch.float32, device=dev, scale=1.7) * sig[0].item()).to(torch.bfloat16)
+    cond = sw.synth_tensor("bench.cond", (1, 16, F_, h, w), torch.float32, device=dev, scale=1.0).to(torch.bfloat16)
+
+    def one_step(i, x):
+        t = model.scheduler.timesteps[i]
+        xs = model.scheduler.scale_model_input(x, timestep=t)
+        out = model.net(x=xs, timesteps=t, latent_condition=cond, context_index=3)
+        model.scheduler.current_step = i
+        return model.scheduler.step(out, t, x).prev_sample
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        xt = one_step(i, xt)
+    barrier()
+    timer = N.KernelTimer() if rank == 0 else None
+    N.set_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        xt = one_step(i, xt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    N.set_timer(None)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tmax.item()
+    assert torch.isfinite(xt.float()).all(), "non-finite latent"
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        steps_s = args.steps / elapsed
+        fl_faithful, fl_exec = dit_flops(S, L=args.blocks), dit_flops(S, L=args.blocks, faithful=False)
+        summ = timer.summary()
+        dom = max(summ, key=lambda k: summ[k]["ms_total"])
+        d = summ[dom]
+        achieved = d["flops"] / (d["ms_total"] * 1e-3) / 1e12        # TFLOP/s over that kernel's launches
+        roofline = {"bound": "mfma", "kernel": {"gemm": "gemm_bf16_kernel", "attention": "attention_fwd_kernel"}[dom],
+                    "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": d["launches"] // args.steps, "avg_launch_ms": round(d["ms_avg"], 4),
+                    "per_kernel": {k: {"tflops": round(v["flops"] / (v["ms_total"] * 1e-3) / 1e12, 1),
+                                       "ms_per_step": round(v["ms_total"] / args.steps, 2)} for k, v in summ.items()}}
+        out = {
+            "metric": "denoising_steps_per_sec", "value": round(steps_s, 4), "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"inverse pass, {args.frames}f x {args.height} x {args.width} clip: EDM Euler step = 1 DiT "
+                                   f"forward (D=4096, {args.blocks} blocks, 32 heads) over S={S} tokens, guidance 0",
+                       "latent": [16, F_, h, w], "tokens": S, "parallelism": f"sp{world} (token bands, K/V all-gather)",
+                       "weights": "random-init (hash generator), 7.2e9 params bf16"},
+            "dit_tflops_reference_equivalent": round(fl_faithful / (ms * 1e-3) / 1e12, 1),
+            "dit_tflops_executed": round(fl_exec / (ms * 1e-3) / 1e12, 1),
+            "mfma_frac_executed": round(fl_exec / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            "frames_per_sec_35step_pass_dit_only": round(args.frames / (35 * ms * 1e-3), 3),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,8 +165,8 @@ extern "C" int drn_rmsnorm(const void* x, const void* w, void* y, int64_t rows, 
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ q, bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
                                                            const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
-                                                           int64_t tokens, int heads, int64_t ld, int64_t tpb,
-                                                           int64_t pos_offset, float eps) {
+                                                           int64_t tokens, int heads, int64_t ldq, int64_t ldk,
+                                                           int64_t tpb, int64_t pos_offset, float eps) {
     const int lane = threadIdx.x & 63;
     const int hr = lane >> 3, j = lane & 7;
     const int hgroups = (heads + 7) / 8;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
         const int64_t tok = r / hgroups;
         const int head = (int)(r - tok * hgroups) * 8 + hr;
         const bool act = head < heads;
-        bf16_t* base = (which ? k : q) + tok * ld + (int64_t)head * 128;
+        bf16_t* base = (which ? k + tok * ldk : q + tok * ldq) + (int64_t)head * 128;
         const bf16_t* w = which ? wk : wq;
         float lo[8], hi[8];
         if (act) {
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
 }
 
 extern "C" int drn_qk_norm_rope(void* q, void* k, const void* wq, const void* wk, const void* cos, const void* sin,
-                                int64_t tokens, int heads, int64_t ld, int64_t tokens_per_batch, int64_t pos_offset,
-                                float eps, void* stream) {
-    DRN_CHECK_ARG(q && k && wq && wk && tokens >= 0 && heads > 0 && ld % 8 == 0 && tokens_per_batch > 0);
+                                int64_t tokens, int heads, int64_t ldq, int64_t ldk, int64_t tokens_per_batch,
+                                int64_t pos_offset, float eps, void* stream) {
+    DRN_CHECK_ARG(q && k && wq && wk && tokens >= 0 && heads > 0 && ldq % 8 == 0 && ldk % 8 == 0 && tokens_per_batch > 0);
     DRN_CHECK_ARG((cos == nullptr) == (sin == nullptr));
     if (tokens == 0) return DRN_OK;
     const int64_t items = tokens * ((heads + 7) / 8) * 2;
@@ -238,7 +238,7 @@ extern "C" int drn_qk_norm_rope(void* q, void* k, const void* wq, const void* wk
     if (blocks > 8192) blocks = 8192;
     qk_norm_rope_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
         (bf16_t*)q, (bf16_t*)k, (const bf16_t*)wq, (const bf16_t*)wk, (const bf16_t*)cos, (const bf16_t*)sin, tokens,
-        heads, ld, tokens_per_batch, pos_offset, eps);
+        heads, ldq, ldk, tokens_per_batch, pos_offset, eps);
     return drn_launch_status();
 }
 
@@ -389,7 +389,8 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const bf16_t* __restri
         if (normalize) {
             const float norm = rbf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]));
             const float den = rbf(fmaxf(norm, 1e-12f));
-            float blend = rbf(rbf(norm - 0.2f) / 0.2f);
+            // torch CPU rounds the Python scalar of a bf16 add/sub to bf16 first (0.2 -> 0.2001953125); div keeps fp32
+            float blend = rbf(rbf(norm - 0.2001953125f) / 0.2f);
             blend = fminf(fmaxf(blend, 0.f), 1.f);
             const float om = rbf(1.0f - blend);
 #pragma unroll

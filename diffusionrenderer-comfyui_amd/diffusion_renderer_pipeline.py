@@ -1,0 +1,134 @@
+"""Drop-in boundary: CleanDiffusionRendererPipeline with the reference's constructor and generate_video
+signatures (diffusion_renderer_pipeline.py:38-111, :242-321).  Shape inference -> config -> (cached) model ->
+sample -> decode -> post-process -> uint8 (B,T,H,W,C) numpy array.
+
+Kept from the reference: attribute knobs (`guidance`, `num_steps`, `seed`, `set_model_type`), the shape-key
+search order, the md5 config cache, every tensor of the batch cast to (device, dtype), ValueError when no usable
+key exists.  Only the pre-loaded-model path is contractual: the reference's dynamic loader calls a method that
+does not exist; here it raises a clear error instead.
+"""
+import hashlib
+import json
+import os
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import native as N
+from .diffusion_renderer_config import get_config_from_tensor_shape, validate_config
+from .model_diffusion_renderer import CleanDiffusionRendererModel
+
+
+class CleanDiffusionRendererPipeline:
+    def __init__(self, checkpoint_dir: str, checkpoint_name: str, model_type: str = "inverse", vae_instance=None,
+                 model_instance=None, guidance: float = 2.0, num_steps: int = 20, height: int = 1024, width: int = 1024,
+                 num_video_frames: int = 1, seed: int = 42, dtype: torch.dtype = torch.bfloat16):
+        self.checkpoint_dir = checkpoint_dir
+        self.checkpoint_name = checkpoint_name
+        self.model_type = model_type.lower() if model_type else None
+        self.vae_instance = vae_instance
+        self.pre_loaded_model_instance = model_instance
+        self.guidance = guidance
+        self.num_steps = num_steps
+        self.default_height = height
+        self.default_width = width
+        self.default_num_video_frames = num_video_frames
+        self.seed = seed
+        self.device = torch.device("cuda")     # torch "cuda" == HIP on ROCm (reference :81)
+        self.dtype = dtype
+        self.config = None
+        self.model = None
+        self._config_cache = {}
+        self._model_cache = {}
+
+    def set_model_type(self, model_type: str):
+        new = model_type.lower()
+        if self.model_type != new:
+            self.model_type = new
+            self.config = None
+            self.model = None
+
+    @staticmethod
+    def _get_config_hash(config) -> str:
+        return hashlib.md5(json.dumps(config, sort_keys=True, default=str).encode()).hexdigest()
+
+    def _ensure_model_loaded(self, input_tensor_shape: tuple):
+        new_config = get_config_from_tensor_shape(self.model_type, input_tensor_shape)
+        new_config["model_type"] = self.model_type
+        h = self._get_config_hash(new_config)
+        if self.config is not None and self._get_config_hash(self.config) == h:
+            return self.model
+        if h in self._model_cache:
+            self.config = new_config
+            self.model = self._model_cache[h]
+            return self.model
+        self.config = new_config
+        validate_config(self.config)
+        if self.pre_loaded_model_instance is not None:
+            self.model = self._configure_pre_loaded_model(self.pre_loaded_model_instance, self.config)
+        else:
+            self.model = self._load_model_with_config()
+        self._model_cache[h] = self.model
+        return self.model
+
+    def _configure_pre_loaded_model(self, model_instance, config):
+        """Re-point a loaded model at a new shape/condition config without touching weights (reference :168-198).
+
+        The weights' own network config (channel counts) stays the model's: the reference rewrites
+        `model.config` wholesale, which silently mismatches in_channels for the forward pass."""
+        net_cfg = model_instance.config.get("net") if isinstance(model_instance.config, dict) else None
+        model_instance.config = dict(config)
+        if net_cfg is not None and model_instance.net is not None:
+            model_instance.config["net"] = net_cfg
+        model_instance.condition_keys = config.get("condition_keys", ["image", "depth", "normal", "basecolor", "roughness", "metallic"])
+        model_instance.condition_drop_rate = config.get("condition_drop_rate", 0.0)
+        model_instance.append_condition_mask = config.get("append_condition_mask", True)
+        model_instance.input_data_key = config.get("input_data_key", "video")
+        if self.vae_instance:
+            model_instance.vae = self.vae_instance
+        return model_instance.to(self.device)
+
+    def _move_to_device(self, data_batch):
+        return {k: (v.to(device=self.device, dtype=self.dtype) if isinstance(v, torch.Tensor) else v)
+                for k, v in data_batch.items()}
+
+    def _load_model_with_config(self):
+        path = os.path.join(self.checkpoint_dir, self.checkpoint_name)
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"checkpoint not found: {path} (pass a pre-loaded model_instance, as the loader node does)")
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        if "model" in sd:
+            sd = sd["model"]
+        model = CleanDiffusionRendererModel(self.config, device=self.device)
+        model.load_state_dict(sd, strict=True)
+        if self.vae_instance:
+            model.vae = self.vae_instance
+        return model
+
+    def generate_video(self, data_batch: Dict[str, torch.Tensor], normalize_normal: bool = False, seed: int = None,
+                       init_noise: torch.Tensor = None) -> np.ndarray:
+        effective_seed = seed if seed is not None else self.seed
+        data_batch = self._move_to_device(data_batch)
+        video_tensor = None
+        for key in ("rgb", "image", "basecolor", "normal", "depth", "roughness", "metallic"):
+            if key in data_batch:
+                video_tensor = data_batch[key]
+                break
+        if video_tensor is None:
+            raise ValueError("No suitable input tensor for shape inference found in data_batch. Looked for "
+                             "['rgb', 'image', 'basecolor', 'normal', 'depth', 'roughness', 'metallic']")
+        self._ensure_model_loaded(tuple(video_tensor.shape))
+        C = self.config["latent_shape"][0]
+        _, _, T, H, W = video_tensor.shape
+        state_shape = [C, (T - 1) // 8 + 1, H // 8, W // 8]
+        sample = self.model.generate_samples_from_batch(data_batch, guidance=self.guidance, state_shape=state_shape,
+                                                        num_steps=self.num_steps, is_negative_prompt=False,
+                                                        seed=effective_seed, init_noise=init_noise)
+        video = self.model.decode(sample)
+        u8 = N.postprocess_u8(video.to(self.dtype).contiguous(), normalize_normal)   # fused :299-318
+        return u8.cpu().numpy()

@@ -25,6 +25,7 @@ import torch
 
 from . import native as N
 from .host_tables import rope_cos_sin, timestep_sinusoid
+from .parallel import ShardPlan, allgather_rows_, group_info
 
 
 def _pad_cols(w: torch.Tensor, mult: int) -> torch.Tensor:
@@ -175,15 +176,22 @@ class HipDiT:
             self._rope_cache[key] = hit
         return hit
 
-    def _workspace(self, S):
-        ws = self._ws.get(S)
+    def _workspace(self, S, rows):
+        """Activation buffers for `rows` local tokens of S total (one shape kept resident)."""
+        key = (S, rows)
+        ws = self._ws.get(key)
         if ws is None:
             D, dev, bf = self.D, self.device, torch.bfloat16
-            ws = {"x": torch.empty((S, D), dtype=bf, device=dev), "h": torch.empty((S, D), dtype=bf, device=dev),
-                  "qkv": torch.empty((S, 3 * D), dtype=bf, device=dev), "o": torch.empty((S, D), dtype=bf, device=dev),
-                  "u": torch.empty((S, int(D * self.net["mlp_ratio"])), dtype=bf, device=dev),
+            ws = {"x": torch.empty((rows, D), dtype=bf, device=dev), "h": torch.empty((rows, D), dtype=bf, device=dev),
+                  "o": torch.empty((rows, D), dtype=bf, device=dev),
+                  "u": torch.empty((rows, int(D * self.net["mlp_ratio"])), dtype=bf, device=dev),
                   "y": torch.empty((S, self.w_final.shape[0]), dtype=bf, device=dev)}
-            self._ws = {S: ws}       # keep one shape resident
+            if rows == S:
+                ws["qkv"] = torch.empty((S, 3 * D), dtype=bf, device=dev)          # q | k | v, fused projection
+            else:
+                ws["q"] = torch.empty((rows, D), dtype=bf, device=dev)             # local queries
+                ws["kv"] = torch.empty((S, 2 * D), dtype=bf, device=dev)           # k | v of ALL tokens (all-gathered)
+            self._ws = {key: ws}
         return ws
 
     # ------------------------------------------------------------------ forward
@@ -193,6 +201,7 @@ class HipDiT:
 
     @torch.no_grad()
     def forward(self, x, timesteps, latent_condition, context_index=None):
+        """net(x, timesteps, latent_condition, context_index) -> [1, out_ch, F, h, w] (full latent on every rank)."""
         dev, bf = self.device, torch.bfloat16
         x = x.to(device=dev, dtype=bf).contiguous()
         cond = latent_condition.to(device=dev, dtype=bf).contiguous()
@@ -206,6 +215,9 @@ class HipDiT:
         D = self.D
         Tp, Hp, Wp = F_ // self.pt, h // self.ps, w // self.ps
         S = Tp * Hp * Wp
+        rank, world = group_info(self.pg) if self.pg is not None else (0, 1)
+        plan = ShardPlan(S, rank, world)
+        rows = plan.rows
 
         mod, modf = self.time_vectors(sigma)
         cvec = self.context_vectors(ci)
@@ -213,11 +225,12 @@ class HipDiT:
             gates = mod[self.ca_sites, 2 * D:]                 # [n_ca, D]
             addvec = gates * cvec                              # bf16(gate * c): the whole cross-attention block
         cos, sin = self.rope(Tp, Hp, Wp)
-        ws = self._workspace(S)
-        X, Hb, QKV, O, U, Y = ws["x"], ws["h"], ws["qkv"], ws["o"], ws["u"], ws["y"]
+        ws = self._workspace(S, rows)
+        X, Hb, O, U, Y = ws["x"], ws["h"], ws["o"], ws["u"], ws["y"]
 
+        # the latent is tiny: every rank patchifies it all and keeps its own token band
         P = N.patchify_concat(x, cond, self.with_mask, self.pt, self.ps, self.kpad)
-        N.gemm(P, self.w_patch, out=X)
+        N.gemm(plan.band(P), self.w_patch, out=X)
 
         pending = None
         site = 0
@@ -237,9 +250,21 @@ class HipDiT:
                 N.ln_modulate(X, shift, scale, out=Hb, add_vec=pending)
                 pending = None
                 if sb["kind"] == "fa":
-                    N.gemm(Hb, sb["wqkv"], out=QKV)
-                    q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
-                    N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads)
+                    if world == 1:
+                        QKV = ws["qkv"]
+                        N.gemm(Hb, sb["wqkv"], out=QKV)
+                        q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
+                        N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads)
+                    else:
+                        # local projections; K|V land directly in this rank's band of the gather buffer
+                        q, KV = ws["q"], ws["kv"]
+                        kv_loc = plan.band(KV)
+                        N.gemm(Hb, sb["wqkv"][:D], out=q)
+                        N.gemm(Hb, sb["wqkv"][D:], out=kv_loc)
+                        N.qk_norm_rope(q, kv_loc[:, :D], sb["qn"], sb["kn"], cos, sin, self.heads,
+                                       tokens_per_batch=rows, pos_offset=plan.start)
+                        allgather_rows_(KV, plan, self.pg)          # the one exchange of the block (RCCL over xGMI)
+                        k, v = KV[:, :D], KV[:, D:]
                     N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
                     N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
                 else:
@@ -249,5 +274,6 @@ class HipDiT:
         if self.trace is not None:
             self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = (X + pending) if pending is not None else X.clone()
         N.ln_modulate(X, modf[:D], modf[D:], out=Hb, add_vec=pending)
-        N.gemm(Hb, self.w_final, out=Y)
+        N.gemm(Hb, self.w_final, out=plan.band(Y))
+        allgather_rows_(Y, plan, self.pg)                           # 2.4 MB at cfg 3: every rank gets the full latent
         return N.unpatchify(Y, 1, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)

@@ -26,7 +26,7 @@ SIGNATURES = {
     "drn_ln_modulate": [_P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
     "drn_bcast_add": [_P, _P, _L, _L, _L, _P],
     "drn_rmsnorm": [_P, _P, _P, _L, _L, _F, _P],
-    "drn_qk_norm_rope": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],
+    "drn_qk_norm_rope": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _F, _P],
     "drn_attention_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "drn_patchify_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "drn_unpatchify": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -85,6 +85,53 @@ def _bf16(*ts):
             assert t.dtype == torch.bfloat16, f"bf16 tensor required, got {t.dtype}"
 
 
+# ----------------------------------------------------------------------------------------------- kernel timing hook
+class KernelTimer:
+    """HIP-event timing of individual launches on the launch stream (bench.py's roofline leg).
+
+    torch.cuda.Event records on torch's current stream, which is the stream every wrapper below launches on.
+    """
+
+    def __init__(self, names=("gemm", "attention")):
+        self.names = set(names)
+        self.records = []          # (name, start_event, end_event, flops, bytes)
+
+    def begin(self, name):
+        if name not in self.names:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, start, flops, nbytes):
+        if start is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((name, start, e, flops, nbytes))
+
+    def summary(self):
+        """name -> dict(launches, ms_total, ms_avg, flops, bytes); call after a synchronize."""
+        out = {}
+        for name, s, e, fl, by in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms_total"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        for d in out.values():
+            d["ms_avg"] = d["ms_total"] / max(d["launches"], 1)
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
 # ----------------------------------------------------------------------------------------------- wrappers
 
 def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_batch=None):
@@ -99,9 +146,12 @@ def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_b
     ldr = residual.stride(0) if residual is not None else 0
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
+    t0 = _TIMER.begin("gemm") if _TIMER is not None else None
     _check(load_library().drn_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
                                         epilogue, _ptr(gate), _ptr(residual), ldr,
                                         rows_per_batch if rows_per_batch else max(M, 1), _stream()), "drn_gemm_bf16")
+    if t0 is not None:
+        _TIMER.end("gemm", t0, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1)))
     return out
 
 
@@ -164,9 +214,9 @@ def qk_norm_rope(q, k, wq, wk, cos, sin, heads, tokens_per_batch=None, pos_offse
     _bf16(q, k, wq, wk, cos, sin)
     tokens = q.shape[0]
     assert q.shape[1] == heads * 128 and k.shape == q.shape and q.stride(1) == 1 and k.stride(1) == 1
-    assert q.stride(0) == k.stride(0)
     _check(load_library().drn_qk_norm_rope(_ptr(q), _ptr(k), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin), tokens, heads,
-                                           q.stride(0), tokens_per_batch if tokens_per_batch else max(tokens, 1),
+                                           q.stride(0), k.stride(0),
+                                           tokens_per_batch if tokens_per_batch else max(tokens, 1),
                                            pos_offset, eps, _stream()), "drn_qk_norm_rope")
 
 
@@ -181,10 +231,13 @@ def attention(q, k, v, out=None, heads=None, scale=None):
         out = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q.device)
     if scale is None:
         scale = 1.0 / (128 ** 0.5)
+    t0 = _TIMER.begin("attention") if _TIMER is not None else None
     _check(load_library().drn_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
                                              q.stride(1), k.stride(1), v.stride(1), out.stride(1),
                                              q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
            "drn_attention_bf16")
+    if t0 is not None:
+        _TIMER.end("attention", t0, 4.0 * B * H * Sq * Sk * 128, 2.0 * B * H * 128 * (2 * Sq + 2 * Sk))
     return out
 
 

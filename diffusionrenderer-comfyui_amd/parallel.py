@@ -1,0 +1,56 @@
+"""Sequence (frame) parallelism of one clip across the GPUs of a node: one process per GPU,
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+New design (the reference has no distributed code).  Every DiT op is token-local
+except self-attention, so the token rows [S, D] are cut into `world` contiguous bands (token order is
+(T H W), hence a band is a run of latent frames when world divides F) and exactly one exchange per
+self-attention block is needed: the all-gather of the post-RMSNorm/RoPE K and V rows.  The bands are
+gathered rank-major, which IS the global token order, so no permutation follows.
+
+xGMI is a full point-to-point mesh (7 links per GPU): an all-gather moves each peer's shard over its own
+link once (S/world * 2D * 2 B per peer: 37.7 MB at S = 18432, world = 8), so it is issued as ONE collective
+per layer on the full [S, 2D] buffer rather than per-head pieces.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class ShardPlan:
+    """Token-band decomposition of S rows over `world` ranks."""
+
+    def __init__(self, S: int, rank: int = 0, world: int = 1):
+        if S % world != 0:
+            raise ValueError(f"token count {S} is not divisible by world size {world}")
+        self.S, self.rank, self.world = S, rank, world
+        self.rows = S // world
+        self.start = rank * self.rows
+        self.stop = self.start + self.rows
+
+    def band(self, t: torch.Tensor) -> torch.Tensor:
+        """Rows of a full [S, ...] tensor owned by this rank (a view)."""
+        return t[self.start:self.stop]
+
+
+def group_info(group=None) -> Tuple[int, int]:
+    if group is None and not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def allgather_rows_(full: torch.Tensor, plan: ShardPlan, group=None, async_op: bool = False):
+    """In-place all-gather: `full` is [S, C] contiguous, this rank's band already holds its rows."""
+    if plan.world == 1:
+        return None
+    assert full.is_contiguous() and full.shape[0] == plan.S
+    return dist.all_gather_into_tensor(full, plan.band(full), group=group, async_op=async_op)
+
+
+def allgather_rows(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """Out-of-place variant: local [S/world, C] -> [S, C]."""
+    if plan.world == 1:
+        return local
+    full = torch.empty((plan.S,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    return full

@@ -81,12 +81,12 @@ int drn_bcast_add(void* x, const void* vec, int64_t rows, int64_t D, int64_t row
 int drn_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t D, float eps, void* stream);
 
 /* ---- per-head RMSNorm(q), RMSNorm(k) + 3-D RoPE, in place (CleanGeneralDIT.py:288-295, :45-84).
- * q,k: [tokens, heads, 128] views with row stride `ld` elements (e.g. the fused QKV GEMM output);
+ * q,k: [tokens, heads, 128] views with row strides ldq / ldk elements (e.g. slices of the fused QKV GEMM output);
  * wq,wk: [128] bf16; cos,sin: [tokens_per_batch, 128] bf16 host-built tables, NULL = no RoPE.
  * rotate_half pairs lane i with i+64.  token t uses table row pos_offset + (t % tokens_per_batch). head_dim must be 128. */
 int drn_qk_norm_rope(void* q, void* k, const void* wq, const void* wk, const void* cos, const void* sin,
-                     int64_t tokens, int heads, int64_t ld, int64_t tokens_per_batch, int64_t pos_offset,
-                     float eps, void* stream);
+                     int64_t tokens, int heads, int64_t ldq, int64_t ldk, int64_t tokens_per_batch,
+                     int64_t pos_offset, float eps, void* stream);
 
 /* ---- non-causal scaled-dot-product attention, head_dim 128, online softmax in fp32, bf16 P for the PV MFMA.
  * Replaces F.scaled_dot_product_attention + the sbhd<->bhsd permutes + the F1 head flatten
