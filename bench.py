@@ -39,11 +39,35 @@ def dit_flops(S, D=4096, L=28, faithful=True):
     return lin + att
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use (affinity mask and cgroup quota, not the machine's core count)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    if "DRN_CPU_THREADS" in os.environ:
+        return max(1, int(os.environ["DRN_CPU_THREADS"]))
+    return min(n, 32)      # a 1-GPU share of the host; oversubscribing a shared box only slows the sample down
+
+
 def cpu_baseline(pkg, S_full, budget_s=40.0):
     """Time the CPU oracle on one full-width block (FA+CA+MLP) and extrapolate x28 (a whole cfg-3 step is minutes)."""
     from oracle import dit_oracle as O
-    torch.set_num_threads(os.cpu_count())
-    cores = torch.get_num_threads()
+    cores = host_cores()
+    torch.set_num_threads(cores)
     net = dict(pkg.diffusion_renderer_config.get_inverse_renderer_config()["net"], num_blocks=1)
     sd = pkg.synthetic_weights.synth_state_dict(net, torch.bfloat16)
     orc = O.DitOracle(sd, net, dtype=torch.bfloat16)

@@ -208,6 +208,11 @@ class HipDiT:
         B, C, F_, h, w = x.shape
         if B != 1:
             raise ValueError("the renderer runs batch 1 (noise is drawn with batch 1, model_diffusion_renderer.py:222)")
+        if cond.shape[0] != B or tuple(cond.shape[2:]) != (F_, h, w):
+            # the reference fails here too: torch.cat of x and latent_condition (CleanGeneralDIT.py:675)
+            raise ValueError(f"latent_condition {tuple(cond.shape)} does not match x {tuple(x.shape)} outside the channel dim")
+        if C + cond.shape[1] + (1 if self.with_mask else 0) != self.net["in_channels"] + self.net.get("additional_concat_ch", 16) + (1 if self.with_mask else 0):
+            raise ValueError("channel count of x | latent_condition does not match the patch-embed weights")
         sigma = float(timesteps.flatten()[0]) if torch.is_tensor(timesteps) else float(timesteps)
         ci = 0
         if self.use_ctx:

@@ -130,3 +130,109 @@ def synth_tensor(name: str, shape, dtype=torch.bfloat16, device="cpu", scale: fl
     for d in shape:
         n *= d
     return (hash_uniform(name, n, device) * scale).reshape(*shape).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ tokenizer
+COSMOS_CV8x8x8 = {      # the reference's VAE_config.json:1-30 (AutoencoderKLCosmos hyper-parameters)
+    "in_channels": 3, "out_channels": 3, "latent_channels": 16,
+    "encoder_block_out_channels": (128, 256, 512, 512), "decode_block_out_channels": (256, 512, 512, 512),
+    "num_layers": 2, "attention_resolutions": (32,), "resolution": 1024, "patch_size": 4, "patch_type": "haar",
+    "spatial_compression_ratio": 8, "temporal_compression_ratio": 8, "scaling_factor": 1.0,
+}
+
+
+def vae_param_shapes(cfg: dict = None) -> Dict[str, tuple]:
+    """name -> shape of an AutoencoderKLCosmos state dict (diffusers >= 0.34 naming; UNVERIFIED offline)."""
+    cfg = cfg or COSMOS_CV8x8x8
+    s: Dict[str, tuple] = {}
+
+    def conv(name, cin, cout, k):
+        s[name + ".weight"] = (cout, cin) + tuple(k)
+        s[name + ".bias"] = (cout,)
+
+    def proj(name, cin, cout):           # CosmosConvProjection3d: (1,3,3) then (3,1,1)
+        conv(name + ".conv_s", cin, cout, (1, 3, 3))
+        conv(name + ".conv_t", cout, cout, (3, 1, 1))
+
+    def norm(name, c):
+        s[name + ".norm.weight"] = (c,)
+        s[name + ".norm.bias"] = (c,)
+
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin)
+        proj(name + ".conv1", cin, cout)
+        norm(name + ".norm2", cout)
+        proj(name + ".conv2", cout, cout)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, (1, 1, 1))
+
+    def attn(name, c):
+        norm(name + ".norm", c)
+        for p in ("to_q", "to_k", "to_v", "to_out.0"):
+            conv(f"{name}.{p}", c, c, (1, 1, 1))
+
+    def mid(name, c):
+        resnet(name + ".resnets.0", c, c)
+        attn(name + ".attentions.0", c)
+        attn(name + ".temp_attentions.0", c)
+        resnet(name + ".resnets.1", c, c)
+
+    ps = cfg["patch_size"]
+    n_sp = int(math.log2(cfg["spatial_compression_ratio"])) - int(math.log2(ps))
+    n_tp = int(math.log2(cfg["temporal_compression_ratio"])) - int(math.log2(ps))
+    enc = tuple(cfg["encoder_block_out_channels"])
+    proj("encoder.conv_in", cfg["in_channels"] * ps ** 3, enc[0])
+    for i in range(len(enc) - 1):
+        for j in range(cfg["num_layers"]):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", enc[i] if j == 0 else enc[i + 1], enc[i + 1])
+        if i < len(enc) - 2:
+            sp, tp = i < n_sp, i < n_tp
+            d = f"encoder.down_blocks.{i}.downsamplers.0"
+            if sp:
+                conv(d + ".conv1", enc[i + 1], enc[i + 1], (1, 3, 3))
+            if tp:
+                conv(d + ".conv2", enc[i + 1], enc[i + 1], (3, 1, 1))
+            if sp or tp:
+                conv(d + ".conv3", enc[i + 1], enc[i + 1], (1, 1, 1))
+    mid("encoder.mid_block", enc[-1])
+    norm("encoder.norm_out", enc[-1])
+    proj("encoder.conv_out", enc[-1], cfg["latent_channels"])
+    conv("quant_conv", cfg["latent_channels"], cfg["latent_channels"], (1, 1, 1))
+    conv("post_quant_conv", cfg["latent_channels"], cfg["latent_channels"], (1, 1, 1))
+    dec = tuple(reversed(cfg["decode_block_out_channels"]))
+    proj("decoder.conv_in", cfg["latent_channels"], dec[0])
+    mid("decoder.mid_block", dec[0])
+    for i in range(len(dec) - 1):
+        for j in range(cfg["num_layers"] + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", dec[i] if j == 0 else dec[i + 1], dec[i + 1])
+        if i < len(dec) - 2:
+            tp = 0 < i < n_tp + 1
+            sp = tp or (i < n_sp and n_sp > n_tp)
+            u = f"decoder.up_blocks.{i}.upsamplers.0"
+            if tp:
+                conv(u + ".conv1", dec[i + 1], dec[i + 1], (3, 1, 1))
+            if sp:
+                conv(u + ".conv2", dec[i + 1], dec[i + 1], (1, 3, 3))
+            if sp or tp:
+                conv(u + ".conv3", dec[i + 1], dec[i + 1], (1, 1, 1))
+    norm("decoder.norm_out", dec[-1])
+    proj("decoder.conv_out", dec[-1], cfg["out_channels"] * ps ** 3)
+    return s
+
+
+def synth_vae_state_dict(cfg: dict = None, dtype=torch.bfloat16, device="cpu") -> Dict[str, torch.Tensor]:
+    """Random-init tokenizer weights (variance-preserving uniform convs, small biases, norm gains near 1)."""
+    sd = {}
+    for name, shape in vae_param_shapes(cfg).items():
+        n = 1
+        for d in shape:
+            n *= d
+        key = "vae." + name
+        if name.endswith(".norm.weight"):
+            sd[name] = (1.0 + 0.1 * hash_uniform(key, n, device)).to(dtype)
+        elif name.endswith(".bias"):
+            sd[name] = (0.05 * hash_uniform(key, n, device)).to(dtype)
+        else:
+            fan_in = n // shape[0]
+            sd[name] = (hash_uniform(key, n, device) * (math.sqrt(3.0) / math.sqrt(fan_in))).reshape(shape).to(dtype)
+    return sd

@@ -118,6 +118,52 @@ int drn_cfg_combine(const void* cond, const void* uncond, void* out, int64_t n, 
  * (1+v).clamp(0,2)/2, permute to (B,T,H,W,C), *255, truncating uint8 cast.  video: [B,3,T,H,W] bf16. Bit-exact. */
 int drn_postprocess_u8(const void* video, void* out_u8, int B, int T, int H, int W, int normalize_normal, void* stream);
 
+/* =====================================================================================================
+ * Cosmos-1.0 CV8x8x8 tokenizer (CleanVAE.py:45-60 -> diffusers.AutoencoderKLCosmos, un-vendored: parity unpinned).
+ * Activations are channels-last bf16, X[t][h][w][c], stored with an optional 1-pixel zero halo in H and W
+ * (`halo` = 0 compact / 1 padded); every kernel writes interior pixels only, so a zero-initialised halo stays zero.
+ * ===================================================================================================== */
+
+/* ---- causal conv3d as an implicit GEMM on MFMA (CosmosCausalConv3d / ConvProjection3d / 1x1x1 convs, and - with a
+ * 1x1x1 kernel over a compact [M,K] matrix - the dense GEMMs of the mid-block attention).
+ *   y[p, n] = bf16(bias[n] + sum x[in(p,tap), c] * w[n, tap*C + c]) (+ residual[p, n], rounded again)
+ *   or, out_f32 != 0:  y_f32[p, n] = alpha * (bias[n] + sum ...)
+ * x: [T][H+2*in_halo][W+2*in_halo][C]; w: [N][kT*kH*kW*C] (tap-major repack of the conv weight); bias: [N] or NULL;
+ * y / residual: [To][Ho+2*out_halo][Wo+2*out_halo][ldc / ldr].  Input pixel of tap (kt,kh,kw) for output (to,ho,wo):
+ *   t = max(to*sT + kt - t_off, 0) (causal replicate padding), h = ho*sH + kh - pad, w = wo*sW + kw - pad
+ * (pad = 1 reads the zero halo).  C % 64 == 0, N % 4 == 0. */
+int drn_conv3d_igemm(const void* x, const void* w, const void* bias, void* y, const void* residual,
+                     int T, int H, int W, int C, int in_halo, int N,
+                     int kT, int kH, int kW, int sT, int sH, int sW, int pad, int t_off,
+                     int To, int Ho, int Wo, int out_halo, int64_t ldc, int64_t ldr,
+                     int out_f32, float alpha, void* stream);
+
+/* ---- CosmosCausalGroupNorm(1 group, per frame) [+ SiLU]: y = [silu](bf16((x-mean)*rstd*gamma + beta)).
+ * workspace: drn_groupnorm_workspace_bytes(frames) bytes of device scratch. */
+int drn_groupnorm_silu(const void* x, const void* gamma, const void* beta, void* y, void* workspace,
+                       int frames, int H, int W, int C, int halo, float eps, int silu, void* stream);
+int64_t drn_groupnorm_workspace_bytes(int frames);
+
+/* ---- 2-level 3-D Haar patching (CosmosPatchEmbed3d, patch 4): video [Cin][T][H][W] planar ->
+ * [ (T+3)/4 ][H/4+2*halo][W/4+2*halo][64*Cin]; and its inverse (CosmosUnpatcher3d) -> [C][4*Tp-3][4*Hq][4*Wq]. */
+int drn_haar_patch(const void* video, void* out, int Cin, int T, int H, int W, int halo, void* stream);
+int drn_haar_unpatch(const void* patches, void* video, int Cimg, int Tp, int Hq, int Wq, int halo, void* stream);
+
+/* ---- resampling helpers of CosmosDownsample3d / CosmosUpsample3d.  mode 0: spatial 2x2 mean, 1: causal temporal
+ * 2-frame mean, 2: temporal nearest x2 minus the first frame, 3: spatial nearest x2. */
+int drn_resample(const void* x, void* y, int mode, int T, int H, int W, int C, int To, int Ho, int Wo, int halo,
+                 void* stream);
+
+/* ---- mid-block attention pieces (1 head of dim C): fp32 row softmax -> bf16, bf16 transpose, causal temporal attention */
+int drn_softmax_rows(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, void* stream);
+int drn_transpose_bf16(const void* x, void* y, int rows, int cols, int64_t ldx, int64_t ldo, void* stream);
+int drn_temporal_attention(const void* q, const void* k, const void* v, void* o, int T, int64_t P, int C, float scale,
+                           void* stream);
+
+/* ---- latent layout moves: planar [C][T][H][W] <-> channels-last [T][H+2*halo][W+2*halo][Cs] (Cs >= C) */
+int drn_planar_to_cl(const void* x, void* y, int C, int T, int H, int W, int Cs, int halo, void* stream);
+int drn_cl_to_planar(const void* x, void* y, int C, int T, int H, int W, int Cs, int halo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

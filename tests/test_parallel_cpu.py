@@ -1,0 +1,138 @@
+"""N > 1 path on CPU: two gloo ranks run the DiT with the token-band decomposition of parallel.py (the same
+ShardPlan / all-gather helpers the HIP engine uses) and must reproduce the unsharded oracle.  This checks what the
+multi-GPU design rests on: every op but self-attention is token-local, the K/V bands gathered rank-major ARE the global
+token order, RoPE rows are offset by the band start, and the gathered output rows unpatchify to the full latent.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from conftest import ROOT, tiny_net
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sharded_forward(orc, O, par, x, t, cond, ci, group):
+    """DitOracle.forward restated over one token band (mirrors HipDiT.forward's structure)."""
+    rank, world = par.group_info(group)
+    dt = orc.dtype
+    D = orc.D
+    ctx = F.embedding(ci.long(), orc.w("context_embedding.weight"))
+    ts = t.to(orc.tables_dtype).flatten()
+    t_emb = O.timestep_sinusoid(ts, D).to(dt)
+    lora = F.linear(F.silu(F.linear(t_emb, orc.w("t_embedder.1.linear_1.weight"))), orc.w("t_embedder.1.linear_2.weight"))
+    emb = O.rms_norm(t_emb, orc.w("affline_norm.weight"))
+    xc = torch.cat([x.to(dt), cond.to(dt), torch.ones(1, 1, *x.shape[2:], dtype=dt)], 1)
+    patches = O.patchify(xc, 1, 2)
+    _, Tp, Hp, Wp, K = patches.shape
+    S = Tp * Hp * Wp
+    plan = par.ShardPlan(S, rank, world)
+    xs = F.linear(plan.band(patches.reshape(S, K)), orc.w("x_embedder.proj.1.weight")).unsqueeze(1)    # [rows,1,D]
+    ang = O.rope_angles(Tp, Hp, Wp, orc.dh, orc.w("pos_embedder.seq"), orc.tables_dtype)
+    cos, sin = O.rope_cos_sin(ang, orc.tables_dtype)
+    cos, sin = plan.band(cos.to(dt)), plan.band(sin.to(dt))                                            # pos_offset = band start
+    cs = ctx.permute(1, 0, 2)
+    for i in range(orc.L):
+        for j, kind in enumerate(orc.kinds):
+            pre = f"blocks.block{i}.blocks.{j}."
+            m = F.linear(F.linear(F.silu(emb), orc.w(pre + "adaLN_modulation.1.weight")),
+                         orc.w(pre + "adaLN_modulation.2.weight")) + lora
+            shift, scale, gate = m.chunk(3, dim=1)
+            h = O.modulate(F.layer_norm(xs, (D,), eps=1e-6), shift, scale)
+            if kind == "mlp":
+                out = orc.mlp(pre + "block.", h)
+            elif kind == "ca":
+                out = orc.attention(pre + "block.attn.", h, cs, None, None)
+            else:
+                a = pre + "block.attn."
+                q = F.linear(h, orc.w(a + "to_q.0.weight")).reshape(plan.rows, 1, orc.Hn, orc.dh)
+                k = F.linear(h, orc.w(a + "to_k.0.weight")).reshape(plan.rows, 1, orc.Hn, orc.dh)
+                v = F.linear(h, orc.w(a + "to_v.0.weight")).reshape(plan.rows, orc.Hn * orc.dh)
+                q = O.apply_rope(O.rms_norm(q, orc.w(a + "to_q.1.weight")), cos, sin)
+                k = O.apply_rope(O.rms_norm(k, orc.w(a + "to_k.1.weight")), cos, sin)
+                kv = torch.zeros(S, 2 * D, dtype=dt)
+                plan.band(kv)[:, :D] = k.reshape(plan.rows, D)
+                plan.band(kv)[:, D:] = v
+                par.allgather_rows_(kv, plan, group)                        # the one exchange of the block
+                kf = kv[:, :D].reshape(S, 1, orc.Hn, orc.dh)
+                vf = kv[:, D:].reshape(S, 1, orc.Hn, orc.dh)
+                o = F.scaled_dot_product_attention(q.permute(1, 2, 0, 3), kf.permute(1, 2, 0, 3), vf.permute(1, 2, 0, 3))
+                o = o.permute(2, 0, 1, 3).reshape(plan.rows, 1, D)
+                out = F.linear(o, orc.w(a + "to_out.0.weight"))
+            xs = xs + gate.unsqueeze(0) * out
+    m = F.linear(F.linear(F.silu(emb), orc.w("final_layer.adaLN_modulation.1.weight")),
+                 orc.w("final_layer.adaLN_modulation.2.weight")) + lora[:, : 2 * D]
+    shift, scale = m.chunk(2, dim=1)
+    xm = F.layer_norm(xs, (D,), eps=1e-6) * (1 + scale.unsqueeze(0)) + shift.unsqueeze(0)
+    y_loc = F.linear(xm, orc.w("final_layer.linear.weight")).squeeze(1)
+    y = par.allgather_rows(y_loc.contiguous(), plan, group)
+    return O.unpatchify(y.reshape(Tp, Hp * Wp, -1), 1, Tp, Hp, Wp, 1, 2, 16)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+        from oracle import dit_oracle as O
+        pkg = load_package()
+        par = pkg.parallel
+        net = tiny_net(pkg, 256, 2, 2)
+        sw = pkg.synthetic_weights
+        sd = sw.synth_state_dict(net, torch.bfloat16)
+        x = sw.synth_tensor("par.x", (1, 16, 2, 8, 8), torch.float32, scale=2.0)
+        cond = sw.synth_tensor("par.c", (1, 16, 2, 8, 8), torch.float32, scale=1.0)
+        t, ci = torch.tensor(1.3), torch.full((1, 1), 2, dtype=torch.long)
+        orc = O.DitOracle(sd, net, dtype=torch.float32)
+        with torch.no_grad():
+            full = orc.forward(x, t, cond, ci)
+            shard = _sharded_forward(orc, O, par, x, t, cond, ci, dist.group.WORLD)
+        err = ((shard - full).norm() / full.norm()).item()
+        # helpers on their own
+        plan = par.ShardPlan(12, rank, world)
+        buf = torch.zeros(12, 3)
+        plan.band(buf)[:] = rank + 1
+        par.allgather_rows_(buf, plan, dist.group.WORLD)
+        ok_gather = bool((buf[:6] == 1).all() and (buf[6:] == 2).all())
+        q.put((rank, err, ok_gather))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_token_band_sharding_equals_unsharded_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    for rank, err, ok in res:
+        assert ok, f"rank {rank}: all-gather layout wrong"
+        assert err < 1e-5, f"rank {rank}: sharded vs unsharded rel-L2 {err}"
+
+
+def test_shard_plan_rejects_uneven_split(pkg):
+    with pytest.raises(ValueError):
+        pkg.parallel.ShardPlan(10, 0, 3)
+    p = pkg.parallel.ShardPlan(18432, 5, 8)
+    assert (p.rows, p.start, p.stop) == (2304, 11520, 13824)
