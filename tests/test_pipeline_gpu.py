@@ -40,16 +40,24 @@ def test_generate_video_matches_reference_pipeline(pkg, gpu, fixture, tag):
                              init_noise=gold["xT"])
     ref = gold["video_u8"].numpy()
     assert video.shape == ref.shape and video.dtype == ref.dtype
-    diff = abs(video.astype(int) - ref.astype(int))
-    print(f"{tag}: uint8 max diff {diff.max()}, mean {diff.mean():.4f}, >2 levels: {(diff > 2).mean():.5f}")
-    assert diff.mean() < 1.0 and (diff > 8).mean() < 0.01
+    # the exact answer both bf16 evaluations approximate: fp32 oracle (bf16 host tables), same x_T, same stub tokenizer
+    from oracle import dit_oracle as O
+    sd = pkg.synthetic_weights.synth_state_dict(net, BF)
+    o32 = O.DitOracle(sd, net, dtype=torch.float32, tables_dtype=BF)
+    with torch.no_grad():
+        x0_32 = O.sample_loop(lambda *a: o32.forward(*a).to(BF), gold["xT"], gold["latent_condition"], ci.to(BF), steps, g)
+        u8_32 = O.postprocess(StubVAE().decode(x0_32 / 0.5), meta["normalize_normal"] == "True").numpy()
+    d_hip = abs(video.astype(int) - u8_32.astype(int))
+    d_ref = abs(ref.astype(int) - u8_32.astype(int))
+    print(f"{tag}: uint8 mean |diff| vs fp32 oracle: hip {d_hip.mean():.4f} (max {d_hip.max()}), reference-bf16 {d_ref.mean():.4f} "
+          f"(max {d_ref.max()}); hip vs reference {abs(video.astype(int) - ref.astype(int)).mean():.4f}")
+    assert d_hip.mean() <= 1.5 * d_ref.mean() + 0.25
     # latent-level check of the sampler against the reference trajectory
-    model.scheduler.set_timesteps(steps)
     x0 = model.generate_samples_from_batch(dict(p._move_to_device(batch)), guidance=g, seed=int(meta["seed"]),
                                            state_shape=list(gold["xT"].shape[1:]), num_steps=steps, init_noise=gold["xT"])
-    e = rel_l2(x0.cpu(), gold["x0"].float())
-    print(f"{tag}: x0 rel-L2 vs reference trajectory {e:.3e}")
-    assert e < 3e-2            # 3-4 bf16 denoising steps of a bf16 net: the reference itself drifts ~1e-2 per forward
+    e_hip, e_ref = rel_l2(x0.cpu(), x0_32.float()), rel_l2(gold["x0"], x0_32.float())
+    print(f"{tag}: x0 rel-L2 vs fp32 oracle: hip {e_hip:.3e}, reference-bf16 {e_ref:.3e}")
+    assert e_hip <= 1.5 * e_ref + 1e-3
     assert torch.equal(model.scheduler.sigmas, gold_sigmas(steps))
 
 
