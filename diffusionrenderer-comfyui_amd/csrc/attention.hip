@@ -20,6 +20,9 @@
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
+#ifndef RESCALE_THR
+#define RESCALE_THR 6.0f   // log2 units
+#endif
 
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
 
@@ -62,6 +65,10 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         const bf16_t* qp = Qb + qrow * ldq + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+        // make the Q loads complete HERE: otherwise hipcc keeps a decreasing vmcnt ladder in front of the QK^T MFMAs of
+        // every iteration (first-iteration hazard), which also drains the next tile's K/V loads far too early
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
     // ---- staging map: 1024 16-byte chunks per tile, two per thread per operand
@@ -76,15 +83,28 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     }
     // named registers (no arrays / lambdas: keeps the in-flight tile in VGPRs, not in a promoted alloca)
     u32x4_t kreg0, kreg1, vreg0, vreg1;
+    const bf16_t* kp0 = Kb + (int64_t)st_row[0] * ldk + st_c[0] * 8;      // advanced by one tile per iteration
+    const bf16_t* kp1 = Kb + (int64_t)st_row[1] * ldk + st_c[1] * 8;
+    const bf16_t* vp0 = Vb + (int64_t)st_row[0] * ldv + st_c[0] * 8;
+    const bf16_t* vp1 = Vb + (int64_t)st_row[1] * ldv + st_c[1] * 8;
+    const int64_t kstep = (int64_t)KVT * ldk, vstep = (int64_t)KVT * ldv;
 #define LOAD_TILE(KV0)                                                                        \
     do {                                                                                      \
-        int64_t r0_ = (KV0) + st_row[0], r1_ = (KV0) + st_row[1];                             \
-        if (r0_ > Sk - 1) r0_ = Sk - 1;                                                       \
-        if (r1_ > Sk - 1) r1_ = Sk - 1;                                                       \
-        kreg0 = *reinterpret_cast<const u32x4_t*>(Kb + r0_ * ldk + st_c[0] * 8);              \
-        vreg0 = *reinterpret_cast<const u32x4_t*>(Vb + r0_ * ldv + st_c[0] * 8);              \
-        kreg1 = *reinterpret_cast<const u32x4_t*>(Kb + r1_ * ldk + st_c[1] * 8);              \
-        vreg1 = *reinterpret_cast<const u32x4_t*>(Vb + r1_ * ldv + st_c[1] * 8);              \
+        if ((KV0) + KVT <= Sk) {                                                              \
+            kreg0 = *reinterpret_cast<const u32x4_t*>(kp0);                                   \
+            vreg0 = *reinterpret_cast<const u32x4_t*>(vp0);                                   \
+            kreg1 = *reinterpret_cast<const u32x4_t*>(kp1);                                   \
+            vreg1 = *reinterpret_cast<const u32x4_t*>(vp1);                                   \
+        } else { /* last, partial tile: clamp rows (masked below) */                          \
+            int64_t r0_ = (KV0) + st_row[0], r1_ = (KV0) + st_row[1];                         \
+            if (r0_ > Sk - 1) r0_ = Sk - 1;                                                   \
+            if (r1_ > Sk - 1) r1_ = Sk - 1;                                                   \
+            kreg0 = *reinterpret_cast<const u32x4_t*>(Kb + r0_ * ldk + st_c[0] * 8);          \
+            vreg0 = *reinterpret_cast<const u32x4_t*>(Vb + r0_ * ldv + st_c[0] * 8);          \
+            kreg1 = *reinterpret_cast<const u32x4_t*>(Kb + r1_ * ldk + st_c[1] * 8);          \
+            vreg1 = *reinterpret_cast<const u32x4_t*>(Vb + r1_ * ldv + st_c[1] * 8);          \
+        }                                                                                     \
+        kp0 += kstep; kp1 += kstep; vp0 += vstep; vp1 += vstep;                               \
     } while (0)
 #define WRITE_TILE(BUF)                                                                       \
     do {                                                                                      \
@@ -159,43 +179,49 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         }
 
         // ---- online softmax (query on the lane; partner lane^32 holds the other 32 keys)
-        float mx = s[0][0];
+        float mx4[4];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+        for (int c = 0; c < 4; ++c) mx4[c] = fmaxf(s[0][c], s[1][c]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-        const float mc = m_new * scale_log2e;
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8_t pb[2][2];
+        for (int r = 4; r < 16; ++r) mx4[r & 3] = fmaxf(mx4[r & 3], fmaxf(s[0][r], s[1][r]));
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        {
+            const uint32_t mb = __float_as_uint(mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // exchange with lane ^ 32, no LDS
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        // deferred rescale: keep the old reference max while the new one is within 2^RESCALE_THR of it (P <= 2^THR, exact
+        // in the final O / l ratio); most tiles then skip the 64-register O rescale.  Wave-uniform decision.
+        if (__any((mx - m_run) * scale_log2e > RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+        }
+        const float mc = m_run * scale_log2e;
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+        // ---- per 32-key sub-tile: P = exp2(.), pack to bf16, then O^T += V^T . P^T; written in this order so the
+        //      exp/cvt VALU work of sub-tile 1 can issue under the (asynchronous) PV MFMAs of sub-tile 0
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 p[r] = __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);
-                psum += p[r];
+                ps4[r & 3] += p[r];
             }
+            bf16x8_t pb[2];
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
                 union { bf16x8_t v; uint32_t u[4]; } cv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cv.u[i] = pack_bf2(p[8 * sidx + 2 * i], p[8 * sidx + 2 * i + 1]);
-                pb[kt2][sidx] = cv.v;
+                pb[sidx] = cv.v;
             }
-        }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
                 const char* vb = vs_ + vrow0 + (32 * kt2 + 16 * sidx) * 256;
@@ -206,10 +232,11 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
                     bf16x8_t vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt2][sidx], acc[dt], 0, 0, 0);
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[sidx], acc[dt], 0, 0, 0);
                 }
             }
         }
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
 
         if (t + 1 < nt) WRITE_TILE(buf ^ 1);
         __syncthreads();

@@ -13,6 +13,7 @@
 // to the per-lane SOURCE address and again on the read (cdna guide rule 21).
 //
 // Workgroup ids are remapped so that each XCD (own L2) walks a contiguous band of tiles, 8 tile-rows deep.
+#include <stdlib.h>
 #include "drn_common.h"
 
 #define BM 128
@@ -155,6 +156,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     }
 }
 
+// gemm256.hip: 256x256x64 ping-pong kernel for the large shapes
+int drn_gemm256_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                         int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
+                         void* stream);
+
+static bool use_gemm256(int64_t M, int64_t N) {
+    static int mode = -1;                       // DRN_GEMM256=0 forces the 128x128 kernel (A/B runs)
+    if (mode < 0) {
+        const char* e = getenv("DRN_GEMM256");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mode == 1 && M >= 1024 && N >= 256 && N % 256 == 0;
+}
+
 extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                              int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
                              int64_t ldr, int64_t rows_per_batch, void* stream) {
@@ -165,6 +180,9 @@ extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, i
     if (epilogue == DRN_EPI_GATE_RES)
         DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
     if (M == 0) return DRN_OK;
+    if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
+    if (use_gemm256(M, N))
+        return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
     DRN_CHECK_ARG(tiles < (1ll << 31));
     dim3 grid((unsigned)tiles), block(256);

@@ -290,3 +290,30 @@ def test_postprocess_all_bf16_values(pkg, gpu):
     v = vals[:n].reshape(1, 3, 1, 1, n // 3).contiguous()
     got = pkg.native.postprocess_u8(v.to(gpu), False).cpu()
     assert torch.equal(got, O.postprocess(v, False))
+
+
+# ------------------------------------------------------------------------------------------------ 256x256 ping-pong GEMM (M >= 1024)
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 256, 64, 0), (1100, 512, 128, 0), (2304, 768, 192, 1), (1537, 256, 320, 2),
+                                       (4096, 1024, 1024, 2)])
+def test_gemm256_kernel(pkg, gpu, M, N, K, epi):
+    a, w = rnd((M, K), gpu, seed=50), rnd((N, K), gpu, K ** -0.5, seed=51)
+    lin = (a.float() @ w.float().t()).to(BF)
+    if epi == 0:
+        out, ref = pkg.native.gemm(a, w), lin
+    elif epi == 1:
+        out, ref = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GELU), F.gelu(lin.cpu()).to(gpu)
+    else:
+        x, gate = rnd((M, N), gpu, seed=52), rnd((1, N), gpu, 0.5, seed=53)
+        ref = x + gate * lin
+        out = x.clone()
+        pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out)
+    ok, msg = ulp_diff_ok(out, ref, max_ulp=2, frac_exact=0.97)
+    assert ok, msg
+
+
+def test_gemm256_identity_asymmetric(pkg, gpu):
+    M = K = 1024
+    N = 256
+    a = torch.eye(M, K, dtype=BF, device=gpu)
+    w = (torch.arange(N * K, device=gpu).reshape(N, K) % 251).to(BF)
+    assert torch.equal(pkg.native.gemm(a, w), w.t().contiguous())

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the two MFMA kernels at the cfg-3 shapes (S=18432, D=4096, 32 heads), random data.
+    python tools/kbench.py [attn] [gemm] [--lib path/to/libdrn_variant.so ...]
+Several --lib arguments are timed interleaved in ONE process (round-robin), as the CDNA guide's rule 24 asks."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["attn", "gemm"])
+    ap.add_argument("--lib", action="append", default=[])
+    ap.add_argument("--S", type=int, default=18432)
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    pkg = load_package()
+    N = pkg.native
+    libs = args.lib or [N.library_path()]
+    handles = []
+    for path in libs:
+        lib = ctypes.CDLL(os.path.abspath(path))
+        for name, at in N.SIGNATURES.items():
+            if hasattr(lib, name):
+                getattr(lib, name).argtypes = at
+        handles.append(lib)
+    dev = torch.device("cuda")
+    S, D, H = args.S, 4096, 32
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+    st = torch.cuda.current_stream().cuda_stream
+    cases = []
+    if "attn" in args.what:
+        qkv = rnd(S, 3 * D)
+        o = torch.empty(S, D, dtype=torch.bfloat16, device=dev)
+        fl = 4.0 * S * S * D
+
+        def run_attn(lib):
+            rc = lib.drn_attention_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(), 1, H, S, S,
+                                        3 * D, 3 * D, 3 * D, D, 0, 0, 0, 0, 128 ** -0.5, st)
+            assert rc == 0, rc
+        cases.append(("attention S=%d" % S, run_attn, fl))
+    if "gemm" in args.what:
+        a = rnd(S, D)
+        for (Nn, K, epi, nm) in [(3 * D, D, 0, "qkv"), (D, D, 2, "out+gate"), (4 * D, D, 1, "mlp1+gelu"), (D, 4 * D, 2, "mlp2+gate")]:
+            A = a if K == D else rnd(S, K, scale=0.3)
+            Wt = rnd(Nn, K, scale=K ** -0.5)
+            C = torch.empty(S, Nn, dtype=torch.bfloat16, device=dev)
+            R = rnd(S, Nn) if epi == 2 else None
+            gate = rnd(1, Nn) if epi == 2 else None
+
+            def run_gemm(lib, A=A, Wt=Wt, C=C, R=R, gate=gate, Nn=Nn, K=K, epi=epi):
+                rc = lib.drn_gemm_bf16(A.data_ptr(), Wt.data_ptr(), C.data_ptr(), S, Nn, K, K, K, Nn, epi,
+                                       gate.data_ptr() if gate is not None else None,
+                                       R.data_ptr() if R is not None else None, Nn, S, st)
+                assert rc == 0, rc
+            cases.append((f"gemm {nm} [{S}x{K}]x[{Nn}x{K}]", run_gemm, 2.0 * S * Nn * K))
+    for name, fn, fl in cases:
+        times = [[] for _ in handles]
+        for lib in handles:
+            fn(lib)
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for i, lib in enumerate(handles):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    fn(lib)
+                e1.record()
+                torch.cuda.synchronize()
+                times[i].append(e0.elapsed_time(e1) / 3)
+        for i, path in enumerate(libs):
+            t = sorted(times[i])
+            med, mn = t[len(t) // 2], t[0]
+            print(f"{name:46s} {os.path.basename(path):28s} median {med:8.3f} ms  {fl/med/1e9:8.1f} TF/s   min {mn:8.3f} ms {fl/mn/1e9:8.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
