@@ -17,6 +17,9 @@
 // Softmax in fp32 (exp2 with the scale folded in), P rounded to bf16 for the PV MFMA, row sum from the fp32 P.
 #include "drn_common.h"
 
+#ifndef EXPV
+#define EXPV 0
+#endif
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, bf16_t* __restrict__ O,
     int heads, int64_t Sq, int64_t Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
     int64_t bsv, int64_t bso, float scale_log2e, int nqb, int total) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * KBYTES];   // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(1024))) char smem[5 * KBYTES];   // K0 K1 V0 V1 V2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,10 +109,10 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         }                                                                                     \
         kp0 += kstep; kp1 += kstep; vp0 += vstep; vp1 += vstep;                               \
     } while (0)
-#define WRITE_TILE(BUF)                                                                       \
+#define WRITE_TILE(KBUF, VBUF)                                                                \
     do {                                                                                      \
-        char* ks__ = smem + (BUF) * KBYTES;                                                   \
-        char* vs__ = smem + (2 + (BUF)) * KBYTES;                                             \
+        char* ks__ = smem + (KBUF) * KBYTES;                                                  \
+        char* vs__ = smem + (2 + (VBUF)) * KBYTES;                                            \
         *reinterpret_cast<u32x4_t*>(ks__ + st_koff[0]) = kreg0;                               \
         *reinterpret_cast<u32x4_t*>(vs__ + st_voff[0]) = vreg0;                               \
         *reinterpret_cast<u32x4_t*>(ks__ + st_koff[1]) = kreg1;                               \
@@ -140,106 +143,122 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    f32x16_t s[2];
+    bf16x8_t pb[2][2];
+
+    // S^T = K . Q^T from K buffer KBUF, then mask keys past Sk (last tile only)
+#define QK_PHASE(KBUF, T)                                                                                          \
+    do {                                                                                                           \
+        const char* ks_ = smem + (KBUF) * KBYTES;                                                                  \
+        _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2) {                                                      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kt2][r] = 0.f;                                        \
+            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                     \
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_ + koff[kt2] + (((2 * ks + lh) ^ kx) << 4)); \
+                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt2], 0, 0, 0);                     \
+            }                                                                                                      \
+        }                                                                                                          \
+        if ((int64_t)((T) + 1) * KVT > Sk) {                                                                       \
+            const int64_t kbase = (int64_t)(T) * KVT + 4 * lh;                                                     \
+            _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2)                                                    \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+                    const int64_t key = kbase + 32 * kt2 + (r & 3) + 8 * (r >> 2);                                 \
+                    if (key >= Sk) s[kt2][r] = -INFINITY;                                                          \
+                }                                                                                                  \
+        }                                                                                                          \
+    } while (0)
+
+    // online softmax (query on the lane; partner lane^32 holds the other 32 keys) -> bf16 P^T fragments pb
+#define SOFTMAX_PHASE()                                                                                            \
+    do {                                                                                                           \
+        float mx4[4];                                                                                              \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) mx4[c] = fmaxf(s[0][c], s[1][c]);                            \
+        _Pragma("unroll") for (int r = 4; r < 16; ++r) mx4[r & 3] = fmaxf(mx4[r & 3], fmaxf(s[0][r], s[1][r]));    \
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));                                            \
+        {                                                                                                          \
+            const uint32_t mb = __float_as_uint(mx);                                                               \
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false); /* lane ^ 32, no LDS */        \
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
+        }                                                                                                          \
+        /* deferred rescale: keep the old reference max while the new one is within 2^RESCALE_THR of it (P <= 2^THR, */ \
+        /* exact in the final O / l ratio); most tiles skip the 64-register O rescale.  Wave-uniform decision.      */ \
+        if (__any((mx - m_run) * scale_log2e > RESCALE_THR)) {                                                     \
+            const float m_new = fmaxf(m_run, mx);                                                                  \
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);                             \
+            m_run = m_new;                                                                                         \
+            l_run *= alpha;                                                                                        \
+            _Pragma("unroll") for (int dt = 0; dt < 4; ++dt)                                                       \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;                                \
+        }                                                                                                          \
+        const float mc = m_run * scale_log2e;                                                                      \
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};                                                                       \
+        _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2) {                                                      \
+            float p[16];                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                       \
+                p[r] = (EXPV & 4) ? (s[kt2][r] * scale_log2e - mc) : __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);                                       \
+                ps4[r & 3] += p[r];                                                                                \
+            }                                                                                                      \
+            _Pragma("unroll") for (int sidx = 0; sidx < 2; ++sidx) {                                               \
+                union { bf16x8_t v; uint32_t u[4]; } cv;                                                           \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) cv.u[i] = pack_bf2(p[8 * sidx + 2 * i], p[8 * sidx + 2 * i + 1]); \
+                pb[kt2][sidx] = cv.v;                                                                              \
+            }                                                                                                      \
+        }                                                                                                          \
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);                                                            \
+    } while (0)
+
+    // O^T += V^T . P^T from V buffer VBUF
+#define PV_PHASE(VBUF)                                                                                             \
+    do {                                                                                                           \
+        const char* vs_ = smem + (2 + (VBUF)) * KBYTES;                                                            \
+        _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2)                                                        \
+            _Pragma("unroll") for (int sidx = 0; sidx < 2; ++sidx) {                                               \
+                const char* vb = vs_ + vrow0 + (32 * kt2 + 16 * sidx) * 256;                                       \
+                _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                 \
+                    const bf16x4_t lo = ds_read_tr16(vb + vcol[dt]);                                               \
+                    const bf16x4_t hi = ds_read_tr16(vb + 8 * 256 + vcol[dt]);                                     \
+                    bf16x8_t vf;                                                                                   \
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];                                    \
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];                                    \
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt2][sidx], acc[dt], 0, 0, 0);        \
+                }                                                                                                  \
+            }                                                                                                      \
+    } while (0)
 
     const int nt = (int)((Sk + KVT - 1) / KVT);
     LOAD_TILE((int64_t)0);
-    WRITE_TILE(0);
+    WRITE_TILE(0, 0);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) LOAD_TILE((int64_t)(t + 1) * KVT);
-
-        const char* ks_ = smem + buf * KBYTES;
-        const char* vs_ = smem + (2 + buf) * KBYTES;
-
-        // ---- S^T = K . Q^T
-        f32x16_t s[2];
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt2][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_ + koff[kt2] + (((2 * ks + lh) ^ kx) << 4));
-                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt2], 0, 0, 0);
-            }
+    // The two waves that share a SIMD (w and w+4) run the SAME tile between two barriers but in rotated order:
+    //   group 0:  QK(t) . softmax(t) . PV(t)            group 1:  PV(t-1) . QK(t) . softmax(t)
+    // so after the barrier one wave's softmax (VALU) overlaps the other's MFMA phases instead of both contending for
+    // the matrix pipe and then both for the VALU.  V is triple-buffered (group 1 still reads V[t-1] while V[t+1] lands).
+    int vcur = 0;                                  // t % 3
+    if (wave < 4) {
+        for (int t = 0; t < nt; ++t) {
+            const int vnext = vcur == 2 ? 0 : vcur + 1;
+            if (!(EXPV & 2) && t + 1 < nt) LOAD_TILE((int64_t)(t + 1) * KVT);
+            QK_PHASE(t & 1, t);
+            SOFTMAX_PHASE();
+            PV_PHASE(vcur);
+            if (!(EXPV & 2) && t + 1 < nt) WRITE_TILE((t + 1) & 1, vnext);
+            if (!(EXPV & 1)) __syncthreads();
+            vcur = vnext;
         }
-
-        // ---- mask keys past Sk (last tile only)
-        if ((int64_t)(t + 1) * KVT > Sk) {
-            const int64_t kbase = (int64_t)t * KVT + 4 * lh;
-#pragma unroll
-            for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t key = kbase + 32 * kt2 + (r & 3) + 8 * (r >> 2);
-                    if (key >= Sk) s[kt2][r] = -INFINITY;
-                }
+    } else {
+        int vprev = 2;
+        for (int t = 0; t < nt; ++t) {
+            const int vnext = vcur == 2 ? 0 : vcur + 1;
+            if (!(EXPV & 2) && t + 1 < nt) LOAD_TILE((int64_t)(t + 1) * KVT);
+            if (t > 0) PV_PHASE(vprev);
+            QK_PHASE(t & 1, t);
+            SOFTMAX_PHASE();
+            if (!(EXPV & 2) && t + 1 < nt) WRITE_TILE((t + 1) & 1, vnext);
+            if (!(EXPV & 1)) __syncthreads();
+            vprev = vcur;
+            vcur = vnext;
         }
-
-        // ---- online softmax (query on the lane; partner lane^32 holds the other 32 keys)
-        float mx4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mx4[c] = fmaxf(s[0][c], s[1][c]);
-#pragma unroll
-        for (int r = 4; r < 16; ++r) mx4[r & 3] = fmaxf(mx4[r & 3], fmaxf(s[0][r], s[1][r]));
-        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-        {
-            const uint32_t mb = __float_as_uint(mx);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // exchange with lane ^ 32, no LDS
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        // deferred rescale: keep the old reference max while the new one is within 2^RESCALE_THR of it (P <= 2^THR, exact
-        // in the final O / l ratio); most tiles then skip the 64-register O rescale.  Wave-uniform decision.
-        if (__any((mx - m_run) * scale_log2e > RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-        }
-        const float mc = m_run * scale_log2e;
-        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
-        // ---- per 32-key sub-tile: P = exp2(.), pack to bf16, then O^T += V^T . P^T; written in this order so the
-        //      exp/cvt VALU work of sub-tile 1 can issue under the (asynchronous) PV MFMAs of sub-tile 0
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);
-                ps4[r & 3] += p[r];
-            }
-            bf16x8_t pb[2];
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                union { bf16x8_t v; uint32_t u[4]; } cv;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cv.u[i] = pack_bf2(p[8 * sidx + 2 * i], p[8 * sidx + 2 * i + 1]);
-                pb[sidx] = cv.v;
-            }
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                const char* vb = vs_ + vrow0 + (32 * kt2 + 16 * sidx) * 256;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x4_t lo = ds_read_tr16(vb + vcol[dt]);
-                    const bf16x4_t hi = ds_read_tr16(vb + 8 * 256 + vcol[dt]);
-                    bf16x8_t vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[sidx], acc[dt], 0, 0, 0);
-                }
-            }
-        }
-        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-
-        if (t + 1 < nt) WRITE_TILE(buf ^ 1);
-        __syncthreads();
+        PV_PHASE(vprev);
     }
 
     // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l

@@ -22,8 +22,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
 
+typedef __bf16 drn_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float drn_f32x2_t __attribute__((ext_vector_type(2)));
+// two f32 -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (two scalar casts cost 2 cvt + shift + or)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    drn_f32x2_t f = {lo, hi};
+    drn_bf16x2_t b = __builtin_convertvector(f, drn_bf16x2_t);
+    return *reinterpret_cast<uint32_t*>(&b);
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
