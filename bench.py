@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--blocks", type=int, default=28, help="debug only; the headline number needs 28")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tokenizer", action="store_true", help="skip the (untimed) tokenizer encode/decode leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +170,35 @@ def main():
         elapsed = tmax.item()
     assert torch.isfinite(xt.float()).all(), "non-finite latent"
 
+    # ---- tokenizer leg (rank 0, outside the timed region): one encode + one decode of the full clip, for frames/s and the
+    #      conv kernel's achieved HBM rate.  Random-init CV8x8x8 weights; synthetic RGB clip resident in HBM.
+    tok = None
+    if rank == 0 and not args.no_tokenizer:
+        vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=dev), device=dev)
+        clip = sw.synth_tensor("bench.rgb", (1, 3, args.frames, args.height, args.width), torch.float32, device=dev).to(torch.bfloat16)
+        vae.decode(vae.encode(clip))                   # warm-up (allocator, code objects)
+        torch.cuda.synchronize()
+        vt = N.KernelTimer(names=("conv",))
+        N.set_timer(vt)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        z = vae.encode(clip)
+        e[1].record()
+        rec = vae.decode(z)
+        e[2].record()
+        torch.cuda.synchronize()
+        N.set_timer(None)
+        u8 = N.postprocess_u8(rec.contiguous(), False)
+        assert u8.shape == (1, args.frames, args.height, args.width, 3)
+        cs = vt.summary()["conv"]
+        tok = {"encode_ms": round(e[0].elapsed_time(e[1]), 2), "decode_ms": round(e[1].elapsed_time(e[2]), 2),
+               "conv_launches": cs["launches"], "conv_ms": round(cs["ms_total"], 2),
+               "conv_tflops": round(cs["flops"] / (cs["ms_total"] * 1e-3) / 1e12, 1),
+               "conv_hbm_gbs_algorithmic": round(cs["bytes"] / (cs["ms_total"] * 1e-3) / 1e9, 1),
+               "hbm_frac": round(cs["bytes"] / (cs["ms_total"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        del vae, clip, z, rec, u8
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         steps_s = args.steps / elapsed
@@ -197,6 +227,9 @@ def main():
             "frames_per_sec_35step_pass_dit_only": round(args.frames / (35 * ms * 1e-3), 3),
             "roofline": roofline,
         }
+        if tok is not None:
+            out["tokenizer"] = tok
+            out["frames_per_sec_35step_pass"] = round(args.frames / ((tok["encode_ms"] + 35 * ms + tok["decode_ms"]) * 1e-3), 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, S)
         print(json.dumps(out), flush=True)

@@ -90,8 +90,23 @@ class CleanDiffusionRendererPipeline:
         return model_instance.to(self.device)
 
     def _move_to_device(self, data_batch):
-        return {k: (v.to(device=self.device, dtype=self.dtype) if isinstance(v, torch.Tensor) else v)
-                for k, v in data_batch.items()}
+        """Every tensor -> (device, dtype) as the reference does (:200-208); the copy of an unchanged source tensor is
+        reused across calls (the inverse node hands the same clip to 5 consecutive passes)."""
+        out = {}
+        cache = self.__dict__.setdefault("_h2d_cache", {})
+        for k, v in data_batch.items():
+            if not isinstance(v, torch.Tensor):
+                out[k] = v
+                continue
+            key = (id(v), v._version, tuple(v.shape), v.dtype)
+            hit = cache.get(key)
+            if hit is None or hit[0] is not v or hit[1].device != self.device:
+                if len(cache) >= 32:
+                    cache.clear()
+                hit = (v, v.to(device=self.device, dtype=self.dtype))
+                cache[key] = hit
+            out[k] = hit[1]
+        return out
 
     def _load_model_with_config(self):
         path = os.path.join(self.checkpoint_dir, self.checkpoint_name)

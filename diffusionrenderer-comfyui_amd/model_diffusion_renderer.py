@@ -104,6 +104,7 @@ class CleanDiffusionRendererModel:
         self.append_condition_mask = config.get("append_condition_mask", True)
         self.input_data_key = config.get("input_data_key", "video")
         self.tokenizer = None
+        self._enc_cache = {}      # (data_ptr, shape, version) -> (tensor ref, latent): the node encodes the SAME clip 5x
 
     # ---- nn.Module-shaped conveniences used by the loader node (nodes.py:103-114 in the reference)
     def eval(self):
@@ -152,6 +153,19 @@ class CleanDiffusionRendererModel:
             raise ValueError(f"Model decode expects a 5D latent (B,C,T,H,W), but got {x.ndim}D.")
         return self.vae.decode(x / self.scheduler.sigma_data)
 
+    def _encode_cached(self, x: Tensor) -> Tensor:
+        """encode(x) with a small identity cache: the inverse node runs 5 G-buffer passes over
+        one clip and the reference re-encodes it every pass (model_diffusion_renderer.py:191); same tensor -> same latent."""
+        key = (x.data_ptr(), tuple(x.shape), x._version, x.dtype, id(self.vae))
+        hit = self._enc_cache.get(key)
+        if hit is not None and hit[0] is x:
+            return hit[1]
+        latent = self.encode(x).contiguous()
+        if len(self._enc_cache) >= 16:
+            self._enc_cache.clear()
+        self._enc_cache[key] = (x, latent)
+        return latent
+
     def prepare_diffusion_renderer_latent_conditions(self, data_batch: Dict[str, Tensor], condition_keys: list = None,
                                                      **kwargs) -> Tensor:
         """Per condition key: encode (or zeros) [+ ones/zeros mask], concat on C (reference :158-197)."""
@@ -178,7 +192,7 @@ class CleanDiffusionRendererModel:
                 if self.append_condition_mask:
                     parts.append(torch.zeros(mask_shape, dtype=ref.dtype, device=ref.device))
             else:
-                state = self.encode(data_batch[actual]).contiguous()
+                state = self._encode_cached(data_batch[actual])
                 parts.append(state)
                 if self.append_condition_mask:
                     parts.append(torch.ones(mask_shape, dtype=state.dtype, device=state.device))

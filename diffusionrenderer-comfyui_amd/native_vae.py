@@ -61,11 +61,21 @@ def conv3d(x: CL, w, bias, N_out, k, stride=(1, 1, 1), pad=0, t_off=None, out: C
     assert w.shape == (N_out, kT * kH * kW * x.C), (w.shape, N_out, k, x.C)
     if residual is not None:
         assert (residual.T, residual.H, residual.W, residual.halo) == (To, Ho, Wo, out.halo)
+    t0 = N._TIMER.begin("conv") if N._TIMER is not None else None
+    if t0 is not None:
+        M = To * Ho * Wo
+        taps = kT * kH * kW
+        # algorithmic bytes: each input / output / residual element once + the weights (im2col reuse is on-chip)
+        nbytes = 2.0 * (x.T * x.H * x.W * x.C + M * N_out * (2 if residual is not None else 1) + N_out * taps * x.C)
+        N._TIMER.end_later = (t0, 2.0 * M * N_out * taps * x.C, nbytes)
     N._check(N.load_library().drn_conv3d_igemm(
         x.t.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.t.data_ptr(),
         residual.t.data_ptr() if residual is not None else None, x.T, x.H, x.W, x.C, x.halo, N_out, kT, kH, kW, sT, sH, sW,
         pad, t_off, To, Ho, Wo, out.halo, out.C, residual.C if residual is not None else 0, 0, 1.0, N._stream()),
         "drn_conv3d_igemm")
+    if t0 is not None:
+        _, fl, by = N._TIMER.end_later
+        N._TIMER.end("conv", t0, fl, by)
     return out
 
 

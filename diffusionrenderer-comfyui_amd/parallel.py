@@ -44,6 +44,13 @@ def allgather_rows_(full: torch.Tensor, plan: ShardPlan, group=None, async_op: b
     if plan.world == 1:
         return None
     assert full.is_contiguous() and full.shape[0] == plan.S
+    if dist.get_backend(group) == "gloo" and full.is_cuda:
+        # test-only path (two ranks sharing one GPU cannot use RCCL): gloo gathers device tensors through host staging
+        parts = [torch.empty_like(plan.band(full)) for _ in range(plan.world)]
+        dist.all_gather(parts, plan.band(full).clone(), group=group)
+        for r, p in enumerate(parts):
+            full[r * plan.rows:(r + 1) * plan.rows].copy_(p)
+        return None
     return dist.all_gather_into_tensor(full, plan.band(full), group=group, async_op=async_op)
 
 

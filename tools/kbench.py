@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--lib", action="append", default=[])
     ap.add_argument("--S", type=int, default=18432)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
     args = ap.parse_args()
     pkg = load_package()
     N = pkg.native
@@ -41,15 +42,16 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     cases = []
     if "attn" in args.what:
-        qkv = rnd(S, 3 * D)
+        Sk = args.Sk or S
+        qkv = rnd(max(S, Sk), 3 * D)
         o = torch.empty(S, D, dtype=torch.bfloat16, device=dev)
-        fl = 4.0 * S * S * D
+        fl = 4.0 * S * Sk * D
 
         def run_attn(lib):
-            rc = lib.drn_attention_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(), 1, H, S, S,
+            rc = lib.drn_attention_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(), 1, H, S, Sk,
                                         3 * D, 3 * D, 3 * D, D, 0, 0, 0, 0, 128 ** -0.5, st)
             assert rc == 0, rc
-        cases.append(("attention S=%d" % S, run_attn, fl))
+        cases.append(("attention Sq=%d Sk=%d" % (S, Sk), run_attn, fl))
     if "gemm" in args.what:
         a = rnd(S, D)
         for (Nn, K, epi, nm) in [(3 * D, D, 0, "qkv"), (D, D, 2, "out+gate"), (4 * D, D, 1, "mlp1+gelu"), (D, 4 * D, 2, "mlp2+gate")]:
