@@ -35,8 +35,9 @@ __device__ __forceinline__ bf16x4_t ds_read_tr16(const char* p) {
 
 __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, bf16_t* __restrict__ O,
-    int heads, int64_t Sq, int64_t Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
-    int64_t bsv, int64_t bso, float scale_log2e, int nqb, int total) {
+    int heads, int64_t Sq, int64_t Sk_total, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
+    int64_t bsv, int64_t bso, float scale_log2e, int nqb, int total, int nsplit, int64_t kv_chunk,
+    float* __restrict__ Opart, float* __restrict__ MLpart) {
     __shared__ __attribute__((aligned(1024))) char smem[5 * KBYTES];   // K0 K1 V0 V1 V2
 
     const int tid = threadIdx.x;
@@ -51,14 +52,22 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         const int q = total >> 3, r = total & 7, xcd = bid & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int bh = pid / nqb;
-    const int qb = pid - bh * nqb;
+    // pid -> ((batch*heads + head) * nsplit + split) * nqb + qblock: the q-blocks sharing one K/V chunk are adjacent
+    const int qb = pid % nqb;
+    const int rest = pid / nqb;
+    const int split = rest % nsplit;
+    const int bh = rest / nsplit;
     const int b = bh / heads, head = bh - b * heads;
     const int64_t q0 = (int64_t)qb * QROWS + wave * 32;
+    // split-KV (flash-decoding style): this workgroup sees keys [kv_begin, kv_begin + Sk) only and, when nsplit > 1, emits an
+    // un-normalised partial (O, m, l) that drn_attention_combine merges.  Used to fill the chip when (q-blocks x heads) is a
+    // poor multiple of the 256 CUs, e.g. the 2304-query bands of 8-way sequence parallelism.
+    const int64_t kv_begin = (int64_t)split * kv_chunk;
+    const int64_t Sk = min(kv_chunk, Sk_total - kv_begin);
 
     const bf16_t* Qb = Q + b * bsq + (int64_t)head * 128;
-    const bf16_t* Kb = Kp + b * bsk + (int64_t)head * 128;
-    const bf16_t* Vb = Vp + b * bsv + (int64_t)head * 128;
+    const bf16_t* Kb = Kp + b * bsk + kv_begin * ldk + (int64_t)head * 128;
+    const bf16_t* Vb = Vp + b * bsv + kv_begin * ldv + (int64_t)head * 128;
 
     // ---- Q fragments: lane (lr, lh) holds Q[q0+lr][16*ks + 8*lh .. +7], ks = 0..7
     bf16x8_t qf[8];
@@ -261,38 +270,116 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         PV_PHASE(vprev);
     }
 
-    // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l
+    // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l   (or the un-normalised partial when the keys are split)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
     const int64_t qrow = q0 + lr;
     if (qrow < Sq) {
-        bf16_t* op = O + b * bso + qrow * ldo + (int64_t)head * 128 + 4 * lh;
+        if (nsplit > 1) {
+            // partial layout: Opart[split][batch][q][heads*128] fp32, MLpart[split][batch][q][heads][2] = (m, l)
+            const int nbatch = total / (nqb * heads * nsplit);
+            const int64_t rowid = ((int64_t)split * nbatch + b) * Sq + qrow;
+            float* op = Opart + rowid * ((int64_t)heads * 128) + (int64_t)head * 128 + 4 * lh;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                uint2 o;
-                o.x = pack_bf2(acc[dt][4 * rg + 0] * inv, acc[dt][4 * rg + 1] * inv);
-                o.y = pack_bf2(acc[dt][4 * rg + 2] * inv, acc[dt][4 * rg + 3] * inv);
-                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rg) = o;
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<float4*>(op + 32 * dt + 8 * rg) =
+                        make_float4(acc[dt][4 * rg + 0], acc[dt][4 * rg + 1], acc[dt][4 * rg + 2], acc[dt][4 * rg + 3]);
+            if (lh == 0) {
+                float2* ml = reinterpret_cast<float2*>(MLpart) + rowid * heads + head;
+                *ml = make_float2(m_run, l_tot);
             }
+        } else {
+            const float inv = 1.0f / l_tot;
+            bf16_t* op = O + b * bso + qrow * ldo + (int64_t)head * 128 + 4 * lh;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    uint2 o;
+                    o.x = pack_bf2(acc[dt][4 * rg + 0] * inv, acc[dt][4 * rg + 1] * inv);
+                    o.y = pack_bf2(acc[dt][4 * rg + 2] * inv, acc[dt][4 * rg + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rg) = o;
+                }
+        }
     }
+}
+
+// merge the nsplit partials of one (row, head): O = sum_s w_s O_s / sum_s w_s l_s,  w_s = 2^((m_s - max m) * scale*log2e)
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ Opart, const float* __restrict__ MLpart,
+                                                                bf16_t* __restrict__ O, int nsplit, int batch, int heads, int64_t Sq,
+                                                                int64_t ldo, int64_t bso, float scale_log2e) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (batch, row, head)
+    const int64_t items = (int64_t)batch * Sq * heads;
+    if (item >= items) return;
+    const int head = (int)(item % heads);
+    const int64_t brow = item / heads;                                       // batch * Sq + row
+    const int64_t b = brow / Sq, row = brow - b * Sq;
+    const int64_t split_stride = (int64_t)batch * Sq;
+    const float2* ml = reinterpret_cast<const float2*>(MLpart);
+    float mmax = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mmax = fmaxf(mmax, ml[(s * split_stride + brow) * heads + head].x);
+    float den = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float2 v = ml[(s * split_stride + brow) * heads + head];
+        const float w = __builtin_amdgcn_exp2f((v.x - mmax) * scale_log2e);
+        den += w * v.y;
+        const float2 o = *reinterpret_cast<const float2*>(Opart + ((s * split_stride + brow) * heads + head) * 128 + 2 * lane);
+        o0 += w * o.x;
+        o1 += w * o.y;
+    }
+    const float inv = 1.0f / den;
+    *reinterpret_cast<uint32_t*>(O + b * bso + row * ldo + (int64_t)head * 128 + 2 * lane) = pack_bf2(o0 * inv, o1 * inv);
+}
+
+static int attention_launch(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t Sq, int64_t Sk,
+                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv,
+                            int64_t bso, float scale, int nsplit, void* workspace, void* stream) {
+    DRN_CHECK_ARG(q && k && v && o && batch > 0 && heads > 0 && Sq >= 0 && Sk > 0 && nsplit >= 1);
+    DRN_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
+    DRN_CHECK_ARG(bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 4 == 0);
+    DRN_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 7) == 0);
+    if (Sq == 0) return DRN_OK;
+    int64_t kv_chunk = Sk;
+    if (nsplit > 1) {
+        DRN_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && batch <= 65535);
+        kv_chunk = ((Sk + nsplit - 1) / nsplit + KVT - 1) / KVT * KVT;
+        nsplit = (int)((Sk + kv_chunk - 1) / kv_chunk);                       // no empty chunk
+    }
+    const int64_t nqb = (Sq + QROWS - 1) / QROWS;
+    const int64_t total = nqb * heads * batch * nsplit;
+    DRN_CHECK_ARG(total < (1ll << 31));
+    const float scale_log2e = scale * 1.44269504088896340736f;
+    float* opart = (float*)workspace;
+    float* mlpart = opart ? opart + (int64_t)nsplit * batch * Sq * heads * 128 : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    // gridDim.y carries the batch count for the partial layout (blocks are indexed by x only)
+    attention_fwd_kernel<<<dim3((unsigned)total, 1, 1), dim3(512), 0, st>>>(
+        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk,
+        bsv, bso, scale_log2e, (int)nqb, (int)total, nsplit, kv_chunk, opart, mlpart);
+    if (nsplit > 1) {
+        const int64_t items = (int64_t)batch * Sq * heads;
+        attention_combine_kernel<<<dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st>>>(opart, mlpart, (bf16_t*)o, nsplit, batch,
+                                                                                            heads, Sq, ldo, bso, scale_log2e);
+    }
+    return drn_launch_status();
 }
 
 extern "C" int drn_attention_bf16(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t Sq,
                                   int64_t Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq,
                                   int64_t bsk, int64_t bsv, int64_t bso, float scale, void* stream) {
-    DRN_CHECK_ARG(q && k && v && o && batch > 0 && heads > 0 && Sq >= 0 && Sk > 0);
-    DRN_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
-    DRN_CHECK_ARG(bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 4 == 0);
-    DRN_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 7) == 0);
-    if (Sq == 0) return DRN_OK;
-    const int64_t nqb = (Sq + QROWS - 1) / QROWS;
-    const int64_t total = nqb * heads * batch;
-    DRN_CHECK_ARG(total < (1ll << 31));
-    const float scale_log2e = scale * 1.44269504088896340736f;
-    attention_fwd_kernel<<<dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream>>>(
-        (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk,
-        bsv, bso, scale_log2e, (int)nqb, (int)total);
-    return drn_launch_status();
+    return attention_launch(q, k, v, o, batch, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale, 1, nullptr, stream);
+}
+
+extern "C" int64_t drn_attention_splitkv_workspace_bytes(int batch, int heads, int64_t Sq, int nsplit) {
+    return (int64_t)nsplit * batch * Sq * heads * (128 + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int drn_attention_splitkv_bf16(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t Sq,
+                                          int64_t Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq,
+                                          int64_t bsk, int64_t bsv, int64_t bso, float scale, int nsplit, void* workspace,
+                                          void* stream) {
+    return attention_launch(q, k, v, o, batch, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale, nsplit, workspace,
+                            stream);
 }

@@ -170,12 +170,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int hr = lane >> 3, j = lane & 7;
     const int hgroups = (heads + 7) / 8;
-    const int64_t items = tokens * hgroups * 2;
+    const int nwhich = (q ? 1 : 0) + (k ? 1 : 0);          // either tensor may be NULL (q and k handled by separate calls)
+    const int64_t items = tokens * hgroups * nwhich;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t it = wave0; it < items; it += nwaves) {
-        const int which = (int)(it & 1);
-        const int64_t r = it >> 1;
+        const int which = nwhich == 2 ? (int)(it & 1) : (q ? 0 : 1);
+        const int64_t r = nwhich == 2 ? (it >> 1) : it;
         const int64_t tok = r / hgroups;
         const int head = (int)(r - tok * hgroups) * 8 + hr;
         const bool act = head < heads;
@@ -230,10 +231,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
 extern "C" int drn_qk_norm_rope(void* q, void* k, const void* wq, const void* wk, const void* cos, const void* sin,
                                 int64_t tokens, int heads, int64_t ldq, int64_t ldk, int64_t tokens_per_batch,
                                 int64_t pos_offset, float eps, void* stream) {
-    DRN_CHECK_ARG(q && k && wq && wk && tokens >= 0 && heads > 0 && ldq % 8 == 0 && ldk % 8 == 0 && tokens_per_batch > 0);
+    DRN_CHECK_ARG((q || k) && (!q || wq) && (!k || wk) && tokens >= 0 && heads > 0 && ldq % 8 == 0 && ldk % 8 == 0 &&
+                  tokens_per_batch > 0);
     DRN_CHECK_ARG((cos == nullptr) == (sin == nullptr));
     if (tokens == 0) return DRN_OK;
-    const int64_t items = tokens * ((heads + 7) / 8) * 2;
+    const int64_t items = tokens * ((heads + 7) / 8) * ((q ? 1 : 0) + (k ? 1 : 0));
     int64_t blocks = (items + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     qk_norm_rope_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(

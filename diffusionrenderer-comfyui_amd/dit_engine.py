@@ -261,14 +261,19 @@ class HipDiT:
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
                         N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads)
                     else:
-                        # local projections; K|V land directly in this rank's band of the gather buffer
+                        # local projections; K|V land directly in this rank's band of the gather buffer.  K|V first, so the
+                        # exchange (RCCL's own stream) overlaps the Q projection + q-norm; wait() orders attention after it.
                         q, KV = ws["q"], ws["kv"]
                         kv_loc = plan.band(KV)
-                        N.gemm(Hb, sb["wqkv"][:D], out=q)
                         N.gemm(Hb, sb["wqkv"][D:], out=kv_loc)
-                        N.qk_norm_rope(q, kv_loc[:, :D], sb["qn"], sb["kn"], cos, sin, self.heads,
+                        N.qk_norm_rope(None, kv_loc[:, :D], None, sb["kn"], cos, sin, self.heads,
                                        tokens_per_batch=rows, pos_offset=plan.start)
-                        allgather_rows_(KV, plan, self.pg)          # the one exchange of the block (RCCL over xGMI)
+                        work = allgather_rows_(KV, plan, self.pg, async_op=True)     # the one exchange of the block (xGMI)
+                        N.gemm(Hb, sb["wqkv"][:D], out=q)
+                        N.qk_norm_rope(q, None, sb["qn"], None, cos, sin, self.heads,
+                                       tokens_per_batch=rows, pos_offset=plan.start)
+                        if work is not None:
+                            work.wait()
                         k, v = KV[:, :D], KV[:, D:]
                     N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
                     N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)

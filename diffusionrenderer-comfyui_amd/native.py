@@ -28,6 +28,8 @@ SIGNATURES = {
     "drn_rmsnorm": [_P, _P, _P, _L, _L, _F, _P],
     "drn_qk_norm_rope": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _F, _P],
     "drn_attention_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
+    "drn_attention_splitkv_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P, _P],
+    "drn_attention_splitkv_workspace_bytes": [_I, _I, _L, _I],
     "drn_patchify_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "drn_unpatchify": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "drn_edm_scale_input": [_P, _P, _L, _F, _P],
@@ -35,7 +37,7 @@ SIGNATURES = {
     "drn_cfg_combine": [_P, _P, _P, _L, _F, _P],
     "drn_postprocess_u8": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"drn_error_string": c_char_p}
+_RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64}
 
 
 def library_path() -> str:
@@ -210,18 +212,42 @@ def rmsnorm(x, w, eps=1e-6):
 
 
 def qk_norm_rope(q, k, wq, wk, cos, sin, heads, tokens_per_batch=None, pos_offset=0, eps=1e-6):
-    """In place on q,k: [tokens, heads*128] views (row stride = q.stride(0))."""
+    """In place on q and/or k: [tokens, heads*128] views with their own row strides; either may be None."""
     _bf16(q, k, wq, wk, cos, sin)
-    tokens = q.shape[0]
-    assert q.shape[1] == heads * 128 and k.shape == q.shape and q.stride(1) == 1 and k.stride(1) == 1
+    ref = q if q is not None else k
+    tokens = ref.shape[0]
+    for t in (q, k):
+        if t is not None:
+            assert t.shape == (tokens, heads * 128) and t.stride(1) == 1
     _check(load_library().drn_qk_norm_rope(_ptr(q), _ptr(k), _ptr(wq), _ptr(wk), _ptr(cos), _ptr(sin), tokens, heads,
-                                           q.stride(0), k.stride(0),
+                                           q.stride(0) if q is not None else 0, k.stride(0) if k is not None else 0,
                                            tokens_per_batch if tokens_per_batch else max(tokens, 1),
                                            pos_offset, eps, _stream()), "drn_qk_norm_rope")
 
 
-def attention(q, k, v, out=None, heads=None, scale=None):
-    """q: [B, Sq, H*128], k/v: [B, Sk, H*128] (token-strided views allowed) -> out [B, Sq, H*128]."""
+_NUM_CUS = 256          # MI355X
+_SPLIT_WS = {}
+
+
+def pick_kv_splits(batch, heads, Sq, Sk) -> int:
+    """Number of key chunks that best fills the CUs: one workgroup = (256 queries, 1 head, 1 chunk), one per CU at a time.
+    Minimises ceil(items / CUs) / nsplit (time in units of an unsplit workgroup); 1 when the unsplit grid already fits."""
+    blocks = batch * heads * ((Sq + 255) // 256)
+    best, best_cost = 1, float(-(-blocks // _NUM_CUS))
+    for n in (2, 4, 8):
+        if Sk // n < 512:
+            break
+        # measured on MI355X (tools/kbench.py --splits): ~4 % of an unsplit workgroup per extra workgroup (prologue, fp32
+        # partial store) and ~6 % for the combine pass
+        cost = -(-(blocks * n) // _NUM_CUS) * (1.0 / n + 0.04) + 0.06
+        if cost < min(best_cost, -(-blocks // _NUM_CUS) * 0.93):
+            best, best_cost = n, cost
+    return best
+
+
+def attention(q, k, v, out=None, heads=None, scale=None, kv_splits=None):
+    """q: [B, Sq, H*128], k/v: [B, Sk, H*128] (token-strided views allowed) -> out [B, Sq, H*128].
+    kv_splits: None = automatic (pick_kv_splits), 1 = single pass, n > 1 = split-KV + combine."""
     _bf16(q, k, v, out)
     B, Sq, HD = q.shape
     Sk = k.shape[1]
@@ -231,11 +257,26 @@ def attention(q, k, v, out=None, heads=None, scale=None):
         out = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q.device)
     if scale is None:
         scale = 1.0 / (128 ** 0.5)
+    ns = pick_kv_splits(B, H, Sq, Sk) if kv_splits is None else int(kv_splits)
     t0 = _TIMER.begin("attention") if _TIMER is not None else None
-    _check(load_library().drn_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
-                                             q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                                             q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
-           "drn_attention_bf16")
+    lib = load_library()
+    if ns > 1:
+        nbytes = lib.drn_attention_splitkv_workspace_bytes(B, H, Sq, ns)
+        key = (q.device, nbytes)
+        ws = _SPLIT_WS.get(key)
+        if ws is None:
+            _SPLIT_WS.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            _SPLIT_WS[key] = ws
+        _check(lib.drn_attention_splitkv_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
+                                              q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                              q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, ns, ws.data_ptr(),
+                                              _stream()), "drn_attention_splitkv_bf16")
+    else:
+        _check(lib.drn_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
+                                      q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+               "drn_attention_bf16")
     if t0 is not None:
         _TIMER.end("attention", t0, 4.0 * B * H * Sq * Sk * 128, 2.0 * B * H * 128 * (2 * Sq + 2 * Sk))
     return out

@@ -83,7 +83,8 @@ int drn_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t D, 
 /* ---- per-head RMSNorm(q), RMSNorm(k) + 3-D RoPE, in place (CleanGeneralDIT.py:288-295, :45-84).
  * q,k: [tokens, heads, 128] views with row strides ldq / ldk elements (e.g. slices of the fused QKV GEMM output);
  * wq,wk: [128] bf16; cos,sin: [tokens_per_batch, 128] bf16 host-built tables, NULL = no RoPE.
- * rotate_half pairs lane i with i+64.  token t uses table row pos_offset + (t % tokens_per_batch). head_dim must be 128. */
+ * rotate_half pairs lane i with i+64.  token t uses table row pos_offset + (t % tokens_per_batch). head_dim must be 128.
+ * Either q or k may be NULL (the sequence-parallel path normalises K first so its all-gather can start early). */
 int drn_qk_norm_rope(void* q, void* k, const void* wq, const void* wk, const void* cos, const void* sin,
                      int64_t tokens, int heads, int64_t ldq, int64_t ldk, int64_t tokens_per_batch,
                      int64_t pos_offset, float eps, void* stream);
@@ -97,6 +98,17 @@ int drn_attention_bf16(const void* q, const void* k, const void* v, void* o,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                        int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
                        float scale, void* stream);
+
+/* ---- same attention with the keys cut into `nsplit` chunks (flash-decoding style): every (q-block, head, chunk) is a
+ * workgroup writing an un-normalised fp32 partial into `workspace`, a second kernel merges them.  Arithmetic per chunk is
+ * that of drn_attention_bf16; used when (q-blocks x heads) under-fills the 256 CUs, e.g. the 2304-query token bands of
+ * 8-way sequence parallelism (288 workgroups -> 2304).  workspace: drn_attention_splitkv_workspace_bytes(...) bytes. */
+int drn_attention_splitkv_bf16(const void* q, const void* k, const void* v, void* o,
+                               int batch, int heads, int64_t Sq, int64_t Sk,
+                               int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                               int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                               float scale, int nsplit, void* workspace, void* stream);
+int64_t drn_attention_splitkv_workspace_bytes(int batch, int heads, int64_t Sq, int nsplit);
 
 /* ---- patchify + channel concat: out[b*T*H*W + (t,h,w), (c r m n)] gathered from x | cond | ones-mask
  * (CleanGeneralDIT.py:669-675, :409-414).  x: [B,Cx,Tl,Hl,Wl], cond: [B,Cc,Tl,Hl,Wl] bf16; with_mask appends the

@@ -317,3 +317,26 @@ def test_gemm256_identity_asymmetric(pkg, gpu):
     a = torch.eye(M, K, dtype=BF, device=gpu)
     w = (torch.arange(N * K, device=gpu).reshape(N, K) % 251).to(BF)
     assert torch.equal(pkg.native.gemm(a, w), w.t().contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ split-KV attention
+@pytest.mark.parametrize("heads,Sq,Sk,ns", [(2, 256, 2048, 2), (4, 300, 4100, 4), (32, 256, 4096, 8)])
+def test_attention_splitkv_matches_single_pass(pkg, gpu, heads, Sq, Sk, ns):
+    q = rnd((1, Sq, heads * 128), gpu, seed=60)
+    k = rnd((1, Sk, heads * 128), gpu, seed=61)
+    v = rnd((1, Sk, heads * 128), gpu, seed=62)
+    k[0, Sk - 5] = (q[0, 3].float() * 30).to(BF)          # a late spike: the chunks end with very different maxima
+    one = pkg.native.attention(q, k, v, heads=heads, kv_splits=1)
+    split = pkg.native.attention(q, k, v, heads=heads, kv_splits=ns)
+    ref = _attn_ref(q, k, v, heads)
+    assert rel_l2(split, ref) < 4e-3 and rel_l2(one, ref) < 4e-3
+    assert (split.float() - one.float()).abs().max().item() < 0.02
+
+
+def test_pick_kv_splits(pkg):
+    f = pkg.native.pick_kv_splits
+    assert f(1, 32, 18432, 18432) == 1          # 2304 workgroups = 9 full rounds
+    assert f(1, 32, 2304, 18432) == 4           # 288 workgroups (2 rounds at 56 %) -> 1152 (4.5 -> 5 quarter rounds)
+    assert f(1, 32, 4608, 18432) == 4
+    assert f(1, 32, 9216, 18432) == 1
+    assert f(1, 2, 128, 128) == 1

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--lib", action="append", default=[])
     ap.add_argument("--S", type=int, default=18432)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--splits", type=int, default=1, help="attention: split-KV chunks (drn_attention_splitkv_bf16)")
     ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
     args = ap.parse_args()
     pkg = load_package()
@@ -47,7 +48,18 @@ def main():
         o = torch.empty(S, D, dtype=torch.bfloat16, device=dev)
         fl = 4.0 * S * Sk * D
 
+        ws = None
+        if args.splits > 1:
+            handles[0].drn_attention_splitkv_workspace_bytes.restype = ctypes.c_int64
+            ws = torch.empty(handles[0].drn_attention_splitkv_workspace_bytes(1, H, S, args.splits), dtype=torch.uint8, device=dev)
+
         def run_attn(lib):
+            if ws is not None:
+                rc = lib.drn_attention_splitkv_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(),
+                                                    1, H, S, Sk, 3 * D, 3 * D, 3 * D, D, 0, 0, 0, 0, 128 ** -0.5, args.splits,
+                                                    ws.data_ptr(), st)
+                assert rc == 0, rc
+                return
             rc = lib.drn_attention_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(), 1, H, S, Sk,
                                         3 * D, 3 * D, 3 * D, D, 0, 0, 0, 0, 128 ** -0.5, st)
             assert rc == 0, rc
