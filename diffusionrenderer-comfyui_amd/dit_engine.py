@@ -128,27 +128,43 @@ class HipDiT:
         self.ca_sites = [i * len(self.kinds) + j for i in range(self.L) for j, k in enumerate(self.kinds) if k == "ca"]
 
     # ------------------------------------------------------------------ per-timestep vectors (K10, K11)
+    def prepare_timesteps(self, sigmas) -> None:
+        """AdaLN vectors of a whole sigma schedule in ONE batched pass (host table -> one H2D copy -> batched GEMVs).
+
+        The sampler knows every sigma before its loop starts; computing their vectors up front keeps host->device copies
+        (which block the host until the stream drains) out of the denoising loop, so kernel launches run ahead of the GPU.
+        Same arithmetic per sigma as the reference evaluates inside every forward (CleanGeneralDIT.py:664-666, :500-505)."""
+        todo = []
+        for s_ in sigmas:
+            k = float(s_)
+            if k not in self._time_cache and k not in todo:
+                todo.append(k)
+        if not todo:
+            return
+        D, B = self.D, len(todo)
+        t_emb = torch.cat([timestep_sinusoid(k, D) for k in todo], 0).to(self.device)        # [B, D]
+        x = t_emb.view(1, B, D)
+        h1 = N.gemv(x, self.w_t1)                                                # linear_1
+        lora = N.gemv(h1, self.w_t2, act=N.ACT_SILU)                             # linear_2(silu(.))   [1,B,3D]
+        emb = N.rmsnorm(t_emb, self.w_affnorm).view(1, B, D)                     # affline_norm
+        a = N.gemv(emb, self.w_a1, act=N.ACT_SILU)                               # [1,B,sites*r]
+        a = a.view(B, self.n_sites, self.r).permute(1, 0, 2).contiguous()        # [sites,B,r]
+        mod = N.gemv(a, self.w_a2, add=lora)                                     # [sites,B,3D]
+        af = N.gemv(emb, self.w_fa1, act=N.ACT_SILU)
+        modf = N.gemv(af, self.w_fa2, add=lora[:, :, : 2 * D].contiguous())      # [1,B,2D]
+        if len(self._time_cache) + B > 512:
+            self._time_cache.clear()
+        for i, k in enumerate(todo):
+            self._time_cache[k] = (mod[:, i, :], modf[0, i])                     # rows stay contiguous: [sites][3D], [2D]
+
     def time_vectors(self, sigma: float):
         """AdaLN vectors for one sigma: mod [sites, 3D] (shift|scale|gate), final [2D].  Cached per sigma."""
         key = float(sigma)
         hit = self._time_cache.get(key)
-        if hit is not None:
-            return hit
-        D = self.D
-        t_emb = timestep_sinusoid(key, D).to(self.device)                        # [1, D]
-        x = t_emb.view(1, 1, D)
-        h1 = N.gemv(x, self.w_t1)                                                # linear_1
-        lora = N.gemv(h1, self.w_t2, act=N.ACT_SILU)                             # linear_2(silu(.)) [1,1,3D]
-        emb = N.rmsnorm(t_emb, self.w_affnorm).view(1, 1, D)                     # affline_norm
-        a = N.gemv(emb, self.w_a1, act=N.ACT_SILU)                               # [1,1,sites*r]
-        mod = N.gemv(a.view(self.n_sites, 1, self.r), self.w_a2, add=lora)       # [sites,1,3D]
-        af = N.gemv(emb, self.w_fa1, act=N.ACT_SILU)
-        modf = N.gemv(af, self.w_fa2, add=lora[:, :, : 2 * D].contiguous())      # [1,1,2D]
-        out = (mod.view(self.n_sites, 3 * D), modf.view(2 * D))
-        if len(self._time_cache) > 256:
-            self._time_cache.clear()
-        self._time_cache[key] = out
-        return out
+        if hit is None:
+            self.prepare_timesteps([key])
+            hit = self._time_cache[key]
+        return hit
 
     def context_vectors(self, context_index) -> Optional[torch.Tensor]:
         """c_i = to_out_i(to_v_i(ctx)) for every cross-attention block: [n_ca, D].  Cached per index (F8)."""

@@ -218,6 +218,7 @@ class CleanDiffusionRendererModel:
             torch.manual_seed(seed)
             condition, uncondition = self._get_conditions(data_batch)
             self.scheduler.set_timesteps(num_steps)
+            self.net.prepare_timesteps([float(t) for t in self.scheduler.timesteps])   # all AdaLN vectors, one batched pass
             if init_noise is not None:
                 xt = init_noise.to(**self._get_tensor_kwargs()).contiguous()
             else:
