@@ -167,7 +167,12 @@ static bool use_gemm256(int64_t M, int64_t N) {
         const char* e = getenv("DRN_GEMM256");
         mode = (e && e[0] == '0') ? 0 : 1;
     }
-    return mode == 1 && M >= 1024 && N >= 256 && N % 256 == 0;
+    if (mode != 1 || M < 256 || N < 256 || N % 256 != 0) return false;
+    // wave-quantisation model (measured on MI355X): a 256^2 workgroup owns a CU for 1 time unit; 128^2 workgroups run two per
+    // CU at ~1000 vs ~1300 TF/s, i.e. a full round of 512 of them takes ~0.65 units
+    const int64_t t256 = ((M + 255) / 256) * (N / 256), t128 = ((M + 127) / 128) * (N / 128);
+    const double c256 = (double)((t256 + 255) / 256), c128 = 0.65 * (double)((t128 + 511) / 512);
+    return c256 <= c128;
 }
 
 extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
