@@ -65,8 +65,13 @@ class CleanDiffusionRendererPipeline:
             return self.model
         self.config = new_config
         validate_config(self.config)
-        if self.pre_loaded_model_instance is not None:
-            self.model = self._configure_pre_loaded_model(self.pre_loaded_model_instance, self.config)
+        inst = self.pre_loaded_model_instance
+        if isinstance(inst, dict):
+            # {"inverse": model, "forward": model}: the two renderers are different checkpoints (in_channels 33 vs 153); the
+            # reference reuses the inverse-built net for both and cannot run the forward pass
+            inst = inst.get(self.model_type)
+        if inst is not None:
+            self.model = self._configure_pre_loaded_model(inst, self.config)
         else:
             self.model = self._load_model_with_config()
         self._model_cache[h] = self.model

@@ -154,12 +154,13 @@ class Cosmos1ForwardRenderer:
             data_batch[key_mapping[name]] = t5.permute(0, 4, 1, 2, 3) * 2.0 - 1.0
         B, _, T, H, W = data_batch["depth"].shape
         data_batch["video"] = data_batch["depth"]
-        # env-map conditions (env_ldr / env_log / env_nrm): one-shot preprocessing outside the denoise loop,
-        # SURVEY.md section 8f rank N4 - not part of the hot path built so far.
-        from . import preprocess_envmap as pe          # raises ImportError until N4 lands
-        env = pe.envmap_conditions(env_map, (H, W), T, env_format, env_brightness, env_flip_horizontal, env_rotation)
-        for k in ("env_ldr", "env_log", "env_nrm"):
-            data_batch[k] = env[k].expand(B, -1, -1, -1, -1) if env[k].shape[2] == T else env[k].expand(B, -1, T, -1, -1)
+        # env-map conditions (env_ldr / env_log / env_nrm): one-shot preprocessing outside the denoise loop (reference :283-304)
+        from . import preprocess_envmap as pe
+        env = pe.envmap_conditions(env_map, (H, W), T, env_format, env_brightness, env_flip_horizontal, env_rotation,
+                                   device=getattr(pipeline, "device", "cuda"))
+        data_batch["env_ldr"] = env["env_ldr"].expand(B, -1, -1, -1, -1)
+        data_batch["env_log"] = env["env_log"].expand(B, -1, -1, -1, -1)
+        data_batch["env_nrm"] = env["env_nrm"].expand(B, -1, T, -1, -1)
         out = pipeline.generate_video(data_batch=data_batch, seed=seed)
         return (torch.from_numpy(out).float() / 255.0,)
 

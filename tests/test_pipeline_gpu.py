@@ -86,3 +86,37 @@ def test_inverse_node_end_to_end_with_hip_tokenizer(pkg, gpu):
     # 4-D batch with N > 1 is rejected like the reference (B must be 1)
     with pytest.raises((ValueError, RuntimeError)):
         node.run_inverse_pass(p, image[0], guidance=0.0, seed=3)
+
+
+def test_forward_node_end_to_end(pkg, gpu):
+    """Cosmos1ForwardRenderer: 5 G-buffers + env map -> 8 encoded conditions (136 ch) -> forward DiT (in_ch 153) -> RGB.
+    The reference cannot run this pass as committed; built by the intent of get_forward_renderer_config."""
+    sw = pkg.synthetic_weights
+    cfgm = pkg.diffusion_renderer_config
+    net = tiny_net(pkg, 256, 1, 2, forward=True)
+    cfg = cfgm.get_forward_renderer_config()
+    cfg["net"] = dict(net)
+    cfg["model_type"] = "forward"
+    model = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(cfg, device=gpu)
+    model.load_state_dict(sw.synth_state_dict(net, BF, device=gpu), strict=True)
+    vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=gpu), device=gpu)
+    p = pkg.diffusion_renderer_pipeline.CleanDiffusionRendererPipeline(
+        "/nonexistent", "x.pt", model_type=None, vae_instance=vae, model_instance={"forward": model}, guidance=0.0, num_steps=2)
+    p.device = gpu
+    node = pkg.NODE_CLASS_MAPPINGS["Cosmos1ForwardRenderer"]()
+    g = {k: sw.synth_tensor("fw." + k, (1, 9, 32, 32, 3), torch.float32).abs() for k in ("depth", "normal", "roughness", "metallic", "base_color")}
+    env = sw.synth_tensor("fw.env", (1, 32, 64, 3), torch.float32).abs() * 4.0
+    (out,) = node.run_forward_pass(p, g["depth"], g["normal"], g["roughness"], g["metallic"], g["base_color"], env,
+                                   guidance=0.0, seed=5, env_format="proj", env_brightness=1.0, env_flip_horizontal=False,
+                                   env_rotation=180.0)
+    assert out.shape == (1, 9, 32, 32, 3) and out.dtype == torch.float32 and 0.0 <= out.min() and out.max() <= 1.0
+    assert model.condition_keys == cfgm.FORWARD_CONDITION_KEYS
+    # an inverse-built net cannot serve the forward pass: clear error instead of the reference's TypeError / shape crash
+    inv_net = tiny_net(pkg, 256, 1, 2)
+    inv = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(dict(cfgm.get_inverse_renderer_config(), net=inv_net), device=gpu)
+    inv.load_state_dict(sw.synth_state_dict(inv_net, BF, device=gpu), strict=True)
+    p2 = pkg.diffusion_renderer_pipeline.CleanDiffusionRendererPipeline("/n", "x.pt", model_type=None, vae_instance=vae,
+                                                                        model_instance=inv, guidance=0.0, num_steps=1)
+    p2.device = gpu
+    with pytest.raises(ValueError, match="channel count"):
+        node.run_forward_pass(p2, g["depth"], g["normal"], g["roughness"], g["metallic"], g["base_color"], env, env_format="ball")
