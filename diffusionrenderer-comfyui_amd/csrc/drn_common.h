@@ -44,6 +44,23 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// erf-GELU of the MLP (nn.GELU(), CleanGeneralDIT.py:446): 0.5 x (1 + erf(x / sqrt 2)).
+// 1 + erf(z) is evaluated as erfc(-z): u = P(t) exp(-z^2), t = 1/(1 + p|z|) (Abramowitz-Stegun 7.1.26, |err| < 1.5e-7), then
+// u for z < 0 (no cancellation in the negative tail) and 2 - u for z >= 0.  ~14 VALU ops instead of libm erff's ~30; the
+// result is rounded to bf16 (2^-9 relative) right after.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float u = p * t * __builtin_amdgcn_exp2f(-1.44269504088896340736f * az * az);
+    const float one_plus_erf = z < 0.f ? u : 2.0f - u;
+    return 0.5f * x * one_plus_erf;
+}
+
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // streaming (read-once) 16-byte load
 __device__ __forceinline__ uint4 ld16_nt(const void* p) {

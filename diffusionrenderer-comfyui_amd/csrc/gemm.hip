@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
             for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r]);
             if (EPI == DRN_EPI_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
             } else if (EPI == DRN_EPI_GATE_RES) {
                 const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);
                 const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
                     for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][mt][j][nt][r]);
                     if (EPI == DRN_EPI_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf256(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
                     } else if (EPI == DRN_EPI_GATE_RES) {
                         const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);
                         const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);
