@@ -18,6 +18,7 @@
 // LDS rows are 128 B (64 bf16 of K); chunk index XOR (row>>1)&7 makes ds_read_b128 conflict-free; the swizzle is applied
 // on the per-lane DMA source address (global_load_lds writes LDS lane-linearly).  MFMA issued as D = Wfrag x Afrag, so a
 // lane owns 4 consecutive output features of one token (8-byte stores).
+#include <stdlib.h>
 #include "drn_common.h"
 
 #define TB 256
@@ -38,7 +39,7 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
-                                                         const bf16_t* R, int64_t ldr, int64_t rpb) {
+                                                         const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * STAGE_BYTES, the ONLY LDS object
 
     const int tid = threadIdx.x;
@@ -58,7 +59,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int GROUP = 4;
     const int width = GROUP * tiles_n;
     const int group_id = pid / width;
     const int first_m = group_id * GROUP;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[i][mt][j][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8_t af[4][2], wf[2][2];   // [mt][ks], [nt][ks]
+    bf16x8_t af[4][2], wf0[2][2], wf1[2][2];   // [mt][ks], W0 / W1 fragments [nt][ks] (W0 lives through phases 1..4)
 
 #define READ_A(STAGE, I)                                                                                \
     do {                                                                                                \
@@ -123,21 +123,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
             af[mt][1] = *reinterpret_cast<const bf16x8_t*>(b_ + (offa ^ 64) + mt * 2048);               \
         }                                                                                               \
     } while (0)
-#define READ_W(STAGE, J)                                                                                \
+#define READ_W(STAGE, J, WF)                                                                            \
     do {                                                                                                \
         const char* b_ = smem + (STAGE) * STAGE_BYTES + (2 + (J)) * HALF_BYTES;                         \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                              \
-            wf[nt][0] = *reinterpret_cast<const bf16x8_t*>(b_ + offw + nt * 2048);                      \
-            wf[nt][1] = *reinterpret_cast<const bf16x8_t*>(b_ + (offw ^ 64) + nt * 2048);               \
+            WF[nt][0] = *reinterpret_cast<const bf16x8_t*>(b_ + offw + nt * 2048);                      \
+            WF[nt][1] = *reinterpret_cast<const bf16x8_t*>(b_ + (offw ^ 64) + nt * 2048);               \
         }                                                                                               \
     } while (0)
-#define MMA(I, J)                                                                                       \
+#define MMA(I, J, WF)                                                                                   \
     do {                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                            \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
-                    acc[I][mt][J][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], af[mt][ks], acc[I][mt][J][nt], 0, 0, 0); \
+                    acc[I][mt][J][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nt][ks], af[mt][ks], acc[I][mt][J][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                  \
     } while (0)
 #define SYNC_THEN_COMPUTE()                                                                             \
@@ -167,27 +167,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int kt = 0; kt < nk; ++kt) {
         const int st = kt & 1;
         // phase 1: (A0, W0)
-        READ_W(st, 0);
+        READ_W(st, 0, wf0);
         __builtin_amdgcn_sched_barrier(0);
         READ_A(st, 0);
         if (kt + 1 < nk) DMA(1, kt + 1);
         SYNC_THEN_COMPUTE();
-        MMA(0, 0);
+        MMA(0, 0, wf0);
         END_PHASE();
         // phase 2: (A0, W1)
-        READ_W(st, 1);
+        READ_W(st, 1, wf1);
         if (kt + 1 < nk) DMA(2, kt + 1);
         SYNC_THEN_COMPUTE();
-        MMA(0, 1);
+        MMA(0, 1, wf1);
         END_PHASE();
         // phase 3: (A1, W1)
         READ_A(st, 1);
         if (kt + 2 < nk) DMA(0, kt + 2);
         SYNC_THEN_COMPUTE();
-        MMA(1, 1);
+        MMA(1, 1, wf1);
         END_PHASE();
-        // phase 4: (A1, W0)
-        READ_W(st, 0);
+        // phase 4: (A1, W0) - W0 fragments are still in registers from phase 1, no LDS reads here
         if (kt + 2 < nk) {
             DMA(3, kt + 2);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // everything up to W0(kt+1) has landed
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         SYNC_THEN_COMPUTE();
-        MMA(1, 0);
+        MMA(1, 0, wf0);
         END_PHASE();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();          // balance G1's extra barrier
@@ -248,9 +247,15 @@ static int launch256(const void* A, const void* W, void* C, int64_t M, int64_t N
     }
     const int64_t tiles = ((M + TB - 1) / TB) * ((N + TB - 1) / TB);
     if (tiles >= (1ll << 31)) return DRN_EINVAL;
+    static int group = 0;
+    if (group == 0) {
+        const char* e = getenv("DRN_GEMM_GROUP");          // tile-rows per L2 band (A/B experiments)
+        group = e ? atoi(e) : 4;
+        if (group < 1) group = 4;
+    }
     gemm256_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
-        ldr, rpb);
+        ldr, rpb, group);
     return drn_launch_status();
 }
 
