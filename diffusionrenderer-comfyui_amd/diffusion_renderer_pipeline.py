@@ -132,6 +132,28 @@ class CleanDiffusionRendererPipeline:
 
     def generate_video(self, data_batch: Dict[str, torch.Tensor], normalize_normal: bool = False, seed: int = None,
                        init_noise: torch.Tensor = None) -> np.ndarray:
+        sample = self._sample(data_batch, seed, init_noise)
+        video = self.model.decode(sample)
+        u8 = N.postprocess_u8(video.to(self.dtype).contiguous(), normalize_normal)   # fused :299-318
+        return u8.cpu().numpy()
+
+    def generate_video_passes(self, data_batch: Dict[str, torch.Tensor], normalize_normal, seed: int = None,
+                              init_noise: torch.Tensor = None):
+        """P G-buffer passes of ONE clip stepped together: `data_batch["context_index"]` is [P, 1], the
+        clip tensors keep batch 1, `normalize_normal` is a sequence of P flags.  Returns the P uint8 arrays generate_video
+        would return for the passes run one after the other (reference nodes.py:191-213): same seed -> same start noise,
+        one encode instead of P, one batched denoiser call per step."""
+        flags = list(normalize_normal)
+        sample = self._sample(data_batch, seed, init_noise)
+        if sample.shape[0] != len(flags):
+            raise ValueError(f"{len(flags)} normalize_normal flags for {sample.shape[0]} passes")
+        outs = []
+        for p, flag in enumerate(flags):
+            video = self.model.decode(sample[p:p + 1])
+            outs.append(N.postprocess_u8(video.to(self.dtype).contiguous(), bool(flag)))
+        return [o.cpu().numpy() for o in outs]
+
+    def _sample(self, data_batch, seed, init_noise):
         effective_seed = seed if seed is not None else self.seed
         data_batch = self._move_to_device(data_batch)
         video_tensor = None
@@ -146,9 +168,6 @@ class CleanDiffusionRendererPipeline:
         C = self.config["latent_shape"][0]
         _, _, T, H, W = video_tensor.shape
         state_shape = [C, (T - 1) // 8 + 1, H // 8, W // 8]
-        sample = self.model.generate_samples_from_batch(data_batch, guidance=self.guidance, state_shape=state_shape,
-                                                        num_steps=self.num_steps, is_negative_prompt=False,
-                                                        seed=effective_seed, init_noise=init_noise)
-        video = self.model.decode(sample)
-        u8 = N.postprocess_u8(video.to(self.dtype).contiguous(), normalize_normal)   # fused :299-318
-        return u8.cpu().numpy()
+        return self.model.generate_samples_from_batch(data_batch, guidance=self.guidance, state_shape=state_shape,
+                                                      num_steps=self.num_steps, is_negative_prompt=False,
+                                                      seed=effective_seed, init_noise=init_noise)

@@ -193,18 +193,19 @@ class HipDiT:
             self._rope_cache[key] = hit
         return hit
 
-    def _workspace(self, S, rows):
-        """Activation buffers for `rows` local tokens of S total (one shape kept resident)."""
-        key = (S, rows)
+    def _workspace(self, S, rows, B=1):
+        """Activation buffers for `rows` local tokens of S total, B clips stacked along the rows (one shape kept resident)."""
+        key = (S, rows, B)
         ws = self._ws.get(key)
         if ws is None:
             D, dev, bf = self.D, self.device, torch.bfloat16
-            ws = {"x": torch.empty((rows, D), dtype=bf, device=dev), "h": torch.empty((rows, D), dtype=bf, device=dev),
-                  "o": torch.empty((rows, D), dtype=bf, device=dev),
-                  "u": torch.empty((rows, int(D * self.net["mlp_ratio"])), dtype=bf, device=dev),
-                  "y": torch.empty((S, self.w_final.shape[0]), dtype=bf, device=dev)}
+            n = B * rows
+            ws = {"x": torch.empty((n, D), dtype=bf, device=dev), "h": torch.empty((n, D), dtype=bf, device=dev),
+                  "o": torch.empty((n, D), dtype=bf, device=dev),
+                  "u": torch.empty((n, int(D * self.net["mlp_ratio"])), dtype=bf, device=dev),
+                  "y": torch.empty((B * S, self.w_final.shape[0]), dtype=bf, device=dev)}
             if rows == S:
-                ws["qkv"] = torch.empty((S, 3 * D), dtype=bf, device=dev)          # q | k | v, fused projection
+                ws["qkv"] = torch.empty((B * S, 3 * D), dtype=bf, device=dev)      # q | k | v, fused projection
             else:
                 ws["q"] = torch.empty((rows, D), dtype=bf, device=dev)             # local queries
                 ws["kv"] = torch.empty((S, 2 * D), dtype=bf, device=dev)           # k | v of ALL tokens (all-gathered)
@@ -218,36 +219,62 @@ class HipDiT:
 
     @torch.no_grad()
     def forward(self, x, timesteps, latent_condition, context_index=None):
-        """net(x, timesteps, latent_condition, context_index) -> [1, out_ch, F, h, w] (full latent on every rank)."""
+        """net(x, timesteps, latent_condition, context_index) -> [B, out_ch, F, h, w] (full latent on every rank).
+
+        B > 1 stacks B clips of one shape and one sigma along the token rows (row = b*S + s): the G-buffer passes of one
+        clip and the cond / uncond halves of classifier-free guidance are such batches.  Every op is
+        row-local except self-attention, which runs per clip (batch stride), so each clip's result is that of its own
+        B = 1 forward.  `context_index`: int, list of B ints or a [B, 1] tensor; `latent_condition` [B or 1, ...]."""
         dev, bf = self.device, torch.bfloat16
         x = x.to(device=dev, dtype=bf).contiguous()
-        cond = latent_condition.to(device=dev, dtype=bf).contiguous()
+        cond = latent_condition.to(device=dev, dtype=bf)
         B, C, F_, h, w = x.shape
-        if B != 1:
-            raise ValueError("the renderer runs batch 1 (noise is drawn with batch 1, model_diffusion_renderer.py:222)")
+        if cond.shape[0] == 1 and B > 1:
+            cond = cond.expand(B, *cond.shape[1:])
+        cond = cond.contiguous()
         if cond.shape[0] != B or tuple(cond.shape[2:]) != (F_, h, w):
             # the reference fails here too: torch.cat of x and latent_condition (CleanGeneralDIT.py:675)
             raise ValueError(f"latent_condition {tuple(cond.shape)} does not match x {tuple(x.shape)} outside the channel dim")
         if C + cond.shape[1] + (1 if self.with_mask else 0) != self.net["in_channels"] + self.net.get("additional_concat_ch", 16) + (1 if self.with_mask else 0):
             raise ValueError("channel count of x | latent_condition does not match the patch-embed weights")
-        sigma = float(timesteps.flatten()[0]) if torch.is_tensor(timesteps) else float(timesteps)
-        ci = 0
+        if torch.is_tensor(timesteps):
+            ts = timesteps.flatten().tolist()
+            if any(float(t) != float(ts[0]) for t in ts):
+                raise ValueError("all clips of a batch share one sigma (the sampler steps them together)")
+            sigma = float(ts[0])
+        else:
+            sigma = float(timesteps)
+        cis = [0] * B
         if self.use_ctx:
-            ci = int(context_index.flatten()[0].item()) if torch.is_tensor(context_index) else int(context_index)
+            if torch.is_tensor(context_index):
+                cis = [int(v) for v in context_index.flatten().tolist()]
+            elif isinstance(context_index, (list, tuple)):
+                cis = [int(v) for v in context_index]
+            else:
+                cis = [int(context_index)]
+            if len(cis) == 1 and B > 1:
+                cis = cis * B
+            if len(cis) != B:
+                raise ValueError(f"context_index has {len(cis)} entries for a batch of {B}")
         D = self.D
         Tp, Hp, Wp = F_ // self.pt, h // self.ps, w // self.ps
         S = Tp * Hp * Wp
         rank, world = group_info(self.pg) if self.pg is not None else (0, 1)
+        if B > 1 and world > 1:
+            # token-band sharding is per clip; a sharded job walks the clips (each still spans every rank)
+            return torch.cat([self.forward(x[b:b + 1], sigma, cond[b:b + 1], cis[b]) for b in range(B)], 0)
         plan = ShardPlan(S, rank, world)
-        rows = plan.rows
 
         mod, modf = self.time_vectors(sigma)
-        cvec = self.context_vectors(ci)
         addvec = None
-        if cvec is not None:
+        if self.n_ca:
             gates = mod[self.ca_sites, 2 * D:]                 # [n_ca, D]
-            addvec = gates * cvec                              # bf16(gate * c): the whole cross-attention block
-        if self._graphable(S, world):
+            if B == 1:
+                addvec = gates * self.context_vectors(cis[0])  # bf16(gate * c): the whole cross-attention block
+            else:
+                cv = torch.stack([self.context_vectors(c) for c in cis], 1)       # [n_ca, B, D]
+                addvec = (gates.unsqueeze(1) * cv).contiguous()
+        if self._graphable(S, world) and B == 1:
             return self._graph_forward(x, cond, mod, modf, addvec, Tp, Hp, Wp)
         return self._run(x, cond, mod, modf, addvec, Tp, Hp, Wp, plan)
 
@@ -288,17 +315,28 @@ class HipDiT:
         g.replay()
         return out.clone()                                       # the graph's output buffer is reused by the next replay
 
+    @staticmethod
+    def _traced(X, pending, B):
+        if pending is None:
+            return X.clone()
+        return (X.view(B, -1, X.shape[1]) + pending.view(B, 1, -1)).view_as(X)
+
     def _run(self, x, cond, mod, modf, addvec, Tp, Hp, Wp, plan):
         """The kernel sequence of one forward (all shapes / pointers fixed for a given input shape -> capturable)."""
         D = self.D
         S, rows, world = plan.S, plan.rows, plan.world
+        B = x.shape[0]                                           # B > 1 only with world == 1 (rows == S)
         cos, sin = self.rope(Tp, Hp, Wp)
-        ws = self._workspace(S, rows)
+        ws = self._workspace(S, rows, B)
         X, Hb, O, U, Y = ws["x"], ws["h"], ws["o"], ws["u"], ws["y"]
+        if B > 1:
+            # shift | scale rows per clip for the batched LayerNorm pass: [sites, 2, B, D] (one sigma -> B equal rows)
+            modB = mod[:, :2 * D].reshape(-1, 2, 1, D).expand(-1, 2, B, D).contiguous()
+            modfB = modf.view(2, 1, D).expand(2, B, D).contiguous()
 
         # the latent is tiny: every rank patchifies it all and keeps its own token band
         P = N.patchify_concat(x, cond, self.with_mask, self.pt, self.ps, self.kpad)
-        N.gemm(plan.band(P), self.w_patch, out=X)
+        N.gemm(plan.band(P) if B == 1 else P, self.w_patch, out=X)
 
         pending = None
         site = 0
@@ -307,22 +345,24 @@ class HipDiT:
             for sb in subs:
                 m = mod[site]
                 shift, scale, gate = m[:D], m[D:2 * D], m[2 * D:]
+                if B > 1:
+                    shift, scale = modB[site, 0], modB[site, 1]
                 if self.trace is not None and site > 0:
-                    self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = (X + pending) if pending is not None else X.clone()
+                    self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = self._traced(X, pending, B)
                 site += 1
                 if sb["kind"] == "ca":
                     if pending is not None:
-                        N.bcast_add(X, pending)
+                        N.bcast_add(X, pending, rows_per_batch=rows)
                     pending = addvec[sb["idx"]]
                     continue
-                N.ln_modulate(X, shift, scale, out=Hb, add_vec=pending)
+                N.ln_modulate(X, shift, scale, out=Hb, add_vec=pending, rows_per_batch=rows)
                 pending = None
                 if sb["kind"] == "fa":
                     if world == 1:
                         QKV = ws["qkv"]
                         N.gemm(Hb, sb["wqkv"], out=QKV)
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
-                        N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads)
+                        N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads, tokens_per_batch=S)
                     else:
                         # local projections; K|V land directly in this rank's band of the gather buffer.  K|V first, so the
                         # exchange (RCCL's own stream) overlaps the Q projection + q-norm; wait() orders attention after it.
@@ -338,15 +378,23 @@ class HipDiT:
                         if work is not None:
                             work.wait()
                         k, v = KV[:, :D], KV[:, D:]
-                    N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
+                    if B == 1:
+                        N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
+                    else:
+                        Q3 = QKV.view(B, S, 3 * D)
+                        N.attention(Q3[:, :, :D], Q3[:, :, D:2 * D], Q3[:, :, 2 * D:], out=O.view(B, S, D), heads=self.heads)
                     N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
                 else:
                     N.gemm(Hb, sb["w1"], out=U, epilogue=N.EPI_GELU)
                     N.gemm(U, sb["w2"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
 
         if self.trace is not None:
-            self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = (X + pending) if pending is not None else X.clone()
-        N.ln_modulate(X, modf[:D], modf[D:], out=Hb, add_vec=pending)
-        N.gemm(Hb, self.w_final, out=plan.band(Y))
-        allgather_rows_(Y, plan, self.pg)                           # 2.4 MB at cfg 3: every rank gets the full latent
-        return N.unpatchify(Y, 1, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)
+            self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = self._traced(X, pending, B)
+        if B == 1:
+            N.ln_modulate(X, modf[:D], modf[D:], out=Hb, add_vec=pending)
+            N.gemm(Hb, self.w_final, out=plan.band(Y))
+            allgather_rows_(Y, plan, self.pg)                       # 2.4 MB at cfg 3: every rank gets the full latent
+        else:
+            N.ln_modulate(X, modfB[0], modfB[1], out=Hb, add_vec=pending, rows_per_batch=rows)
+            N.gemm(Hb, self.w_final, out=Y)
+        return N.unpatchify(Y, B, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)

@@ -225,15 +225,36 @@ class CleanDiffusionRendererModel:
                 xt = torch.randn(size=(1, *state_shape), **self._get_tensor_kwargs()) * self.scheduler.sigmas[0]
             cond = condition.to_dict()
             unc = uncondition.to_dict()
-            # the context index is a host scalar for the whole loop (no per-step .item() sync)
+            # the context indices are host scalars for the whole loop (no per-step .item() sync).  P > 1 indices over ONE
+            # clip = P G-buffer passes stepped together: the reference runs them one after the other from
+            # the same seed, i.e. from the same noise, so the batch starts from P copies of xt.
+            cis = [0]
             if "context_index" in cond:
-                cond = dict(cond, context_index=int(cond["context_index"].flatten()[0].item()))
-                unc = dict(unc, context_index=0)
+                cis = [int(v) for v in cond["context_index"].flatten().tolist()]
+            P = len(cis)
+            if xt.shape[0] == 1 and P > 1:
+                xt = xt.expand(P, *xt.shape[1:]).contiguous()
+            if xt.shape[0] != P:
+                raise ValueError(f"{P} context indices for a latent batch of {xt.shape[0]}")
+            lat_c = cond["latent_condition"]
+            if lat_c.shape[0] != 1:
+                # as in the reference, whose batch-1 noise cannot be concatenated with a batch-B condition (:222)
+                raise ValueError("the renderer runs one clip per call (noise is drawn with batch 1)")
+            if P > 1:
+                lat_c = lat_c.expand(P, *lat_c.shape[1:])
+            if guidance > 0:
+                # cond and uncond halves as one batch of 2P clips (uncond = zero condition latent, index 0: reference :92-96)
+                lat = torch.cat([lat_c, torch.zeros_like(lat_c)], 0)
+                idx = cis + [0] * P
+            else:
+                lat, idx = lat_c, cis
             for t in self.scheduler.timesteps:
                 xt_scaled = self.scheduler.scale_model_input(xt, timestep=t)
-                net_output = self.net(x=xt_scaled, timesteps=t, **cond)
                 if guidance > 0:
-                    net_uncond = self.net(x=xt_scaled, timesteps=t, **unc)
-                    net_output = N.cfg_combine(net_output, net_uncond, float(guidance))
+                    both = self.net(x=torch.cat([xt_scaled, xt_scaled], 0), timesteps=t, latent_condition=lat,
+                                    context_index=idx)
+                    net_output = N.cfg_combine(both[:P].contiguous(), both[P:].contiguous(), float(guidance))
+                else:
+                    net_output = self.net(x=xt_scaled, timesteps=t, latent_condition=lat, context_index=idx)
                 xt = self.scheduler.step(net_output, t, xt).prev_sample
             return xt

@@ -108,6 +108,25 @@ class Cosmos1InverseRenderer:
         image_tensor = image_5d.permute(0, 4, 1, 2, 3) * 2.0 - 1.0
         outputs = {}
         pbar = _progress_bar(len(INVERSE_PASSES))
+
+        def to_image(out):
+            t = torch.from_numpy(out).float() / 255.0
+            b, tt, h, w, c = t.shape
+            return t.reshape(b * tt, h, w, c)
+
+        if image_tensor.shape[0] == 1 and getattr(pipeline, "batch_passes", True) and hasattr(pipeline, "generate_video_passes"):
+            # the five passes share the clip, the seed and every weight: step them as one batch
+            data_batch = {
+                "rgb": image_tensor,
+                "video": image_tensor,
+                "context_index": torch.tensor([[GBUFFER_INDEX_MAPPING[p]] for p in INVERSE_PASSES], dtype=torch.long),
+            }
+            outs = pipeline.generate_video_passes(data_batch=data_batch, seed=seed,
+                                                  normalize_normal=[p == "normal" for p in INVERSE_PASSES])
+            for gbuffer_pass, out in zip(INVERSE_PASSES, outs):
+                outputs[gbuffer_pass] = to_image(out)
+                pbar.update(1)
+            return (outputs["basecolor"], outputs["metallic"], outputs["roughness"], outputs["normal"], outputs["depth"])
         for gbuffer_pass in INVERSE_PASSES:
             data_batch = {
                 "rgb": image_tensor,
@@ -115,9 +134,7 @@ class Cosmos1InverseRenderer:
                 "context_index": torch.full((image_tensor.shape[0], 1), GBUFFER_INDEX_MAPPING[gbuffer_pass], dtype=torch.long),
             }
             out = pipeline.generate_video(data_batch=data_batch, normalize_normal=(gbuffer_pass == "normal"), seed=seed)
-            t = torch.from_numpy(out).float() / 255.0
-            b, tt, h, w, c = t.shape
-            outputs[gbuffer_pass] = t.reshape(b * tt, h, w, c)
+            outputs[gbuffer_pass] = to_image(out)
             pbar.update(1)
         return (outputs["basecolor"], outputs["metallic"], outputs["roughness"], outputs["normal"], outputs["depth"])
 

@@ -87,3 +87,30 @@ def test_dit_full_28_blocks_cfg1(pkg, gpu):
     e_ref, e_hip = rel_l2(gold["out.bf16"], exact), rel_l2(y, exact)
     print(f"full28: e_ref={e_ref:.3e} e_hip={e_hip:.3e}")
     assert e_hip <= max(1.5 * e_ref, 1e-3)
+
+
+def test_batched_forward_equals_per_clip_forwards(pkg, gpu):
+    """B clips stacked along the token rows (G-buffer passes / CFG halves): every op is row-local except
+    self-attention, which is per clip, so clip b of the batch must reproduce its own B = 1 forward."""
+    net = tiny_net(pkg, 512, 2, 4)
+    sw = pkg.synthetic_weights
+    dit = pkg.dit_engine.HipDiT(net, sw.synth_state_dict(net, torch.bfloat16, device=gpu), device=gpu)
+    B, F_, h, w = 3, 2, 16, 16
+    x = sw.synth_tensor("bat.x", (B, 16, F_, h, w), torch.float32, scale=2.0).to(torch.bfloat16).to(gpu)
+    cond = sw.synth_tensor("bat.c", (B, net["additional_concat_ch"], F_, h, w), torch.float32, scale=1.0).to(torch.bfloat16).to(gpu)
+    cis = [0, 3, 4]
+    yb = dit(x, torch.tensor(1.25), cond, torch.tensor(cis).view(B, 1))
+    assert yb.shape == (B, 16, F_, h, w)
+    for b in range(B):
+        y1 = dit(x[b:b + 1], torch.tensor(1.25), cond[b:b + 1], cis[b])
+        d = rel_l2(yb[b:b + 1].cpu(), y1.cpu())
+        print(f"clip {b}: batched vs single rel-L2 {d:.3e}, bit-identical {torch.equal(yb[b:b + 1], y1)}")
+        assert d <= 1e-3
+    # clips differ (different conditions / context rows), and a shared condition broadcasts
+    assert rel_l2(yb[0:1].cpu(), yb[1:2].cpu()) > 1e-2
+    y_shared = dit(x, torch.tensor(1.25), cond[:1], cis)
+    assert rel_l2(y_shared[0:1].cpu(), yb[0:1].cpu()) <= 1e-3
+    with pytest.raises(ValueError):
+        dit(x, torch.tensor([1.0, 2.0, 3.0]), cond, cis)          # one sigma per batch
+    with pytest.raises(ValueError):
+        dit(x, torch.tensor(1.0), cond, [0, 1])                   # one index per clip
