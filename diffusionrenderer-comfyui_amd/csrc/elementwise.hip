@@ -124,6 +124,31 @@ extern "C" int drn_bcast_add(void* x, const void* vec, int64_t rows, int64_t D, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// y[b][a][:] = x[a][b][:], 16-byte chunks (regroup around the sequence-parallel all-to-all; C >= 512 in practice, so every
+// run of C elements is a coalesced >= 1 KB read and write)
+__global__ __launch_bounds__(256) void permute_021_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int64_t A,
+                                                          int64_t B, int64_t cch) {
+    const int64_t n = A * B * cch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = i % cch;
+        const int64_t ba = i / cch;           // = b * A + a  (output order)
+        const int64_t a = ba % A, b = ba / A;
+        y[i] = x[(a * B + b) * cch + c];
+    }
+}
+
+extern "C" int drn_permute_021(const void* x, void* y, int64_t A, int64_t B, int64_t C, void* stream) {
+    DRN_CHECK_ARG(x && y && x != y && A >= 0 && B >= 0 && C > 0 && C % 8 == 0);
+    DRN_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
+    const int64_t n = A * B * (C / 8);
+    if (n == 0) return DRN_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    permute_021_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const uint4*)x, (uint4*)y, A, B, C / 8);
+    return drn_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // RMSNorm over the last dim (CleanGeneralDIT.py:14-33).  One wave per row, any D % 8 == 0.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                       bf16_t* __restrict__ y, int64_t rows, int D, float eps) {

@@ -17,7 +17,9 @@ The block reduces to x += bf16(gate * c_i) with c_i cached per context index, an
 fused into the next sub-block's LayerNorm pass.
 
 Sequence parallelism (one process per GPU): rank r owns a contiguous band of latent frames; every op is
-token-local except self-attention, whose K/V rows (after RMSNorm + RoPE) are all-gathered over RCCL.
+token-local except self-attention.  There the ranks trade token bands for heads with one all-to-all (each rank
+attends over ALL tokens of heads/world heads) and trade back afterwards; when the world size does not divide the
+head count, K/V rows (after RMSNorm + RoPE) are all-gathered instead (parallel.py).
 """
 from typing import Dict, Optional
 
@@ -25,7 +27,7 @@ import torch
 
 from . import native as N
 from .host_tables import rope_cos_sin, timestep_sinusoid
-from .parallel import ShardPlan, allgather_rows_, group_info
+from .parallel import ShardPlan, allgather_rows_, alltoall_rows_, group_info
 
 
 def _pad_cols(w: torch.Tensor, mult: int) -> torch.Tensor:
@@ -66,6 +68,15 @@ class HipDiT:
             raise ValueError("HipDiT kernels are specialised for head_dim 128 (the renderer's only configuration)")
         N.load_library()
         self.pg = process_group
+        import os
+        world = group_info(process_group)[1] if process_group is not None else 1
+        mode = os.environ.get("DRN_SP_EXCHANGE", "auto")
+        if mode not in ("auto", "a2a", "gather"):
+            raise ValueError("DRN_SP_EXCHANGE must be auto, a2a or gather")
+        if mode == "a2a" and self.heads % world:
+            raise ValueError(f"head all-to-all needs the world size ({world}) to divide the head count ({self.heads})")
+        self.exchange = "none" if world == 1 else ("gather" if mode == "gather" or self.heads % world else "a2a")
+        self.world = world
         self._load(state_dict, prefix)
         self._rope_cache = {}
         self._time_cache = {}
@@ -104,9 +115,15 @@ class HipDiT:
                 a2.append(g(q + "adaLN_modulation.2.weight"))
                 if kind == "fa":
                     a = q + "block.attn."
-                    subs.append({"kind": "fa",
-                                 "wqkv": torch.cat([g(a + "to_q.0.weight"), g(a + "to_k.0.weight"),
-                                                    g(a + "to_v.0.weight")], 0).contiguous(),
+                    wq, wk, wv = g(a + "to_q.0.weight"), g(a + "to_k.0.weight"), g(a + "to_v.0.weight")
+                    if self.exchange == "a2a":
+                        # output columns grouped by the rank that will own the heads: [rank][q | k | v][heads/world * 128]
+                        W = self.D // self.world
+                        wqkv = torch.stack([wq.view(self.world, W, -1), wk.view(self.world, W, -1),
+                                            wv.view(self.world, W, -1)], 1).reshape(3 * self.D, -1).contiguous()
+                    else:
+                        wqkv = torch.cat([wq, wk, wv], 0).contiguous()
+                    subs.append({"kind": "fa", "wqkv": wqkv,
                                  "qn": g(a + "to_q.1.weight").contiguous(), "kn": g(a + "to_k.1.weight").contiguous(),
                                  "wo": g(a + "to_out.0.weight").contiguous()})
                 elif kind == "ca":
@@ -206,6 +223,13 @@ class HipDiT:
                   "y": torch.empty((B * S, self.w_final.shape[0]), dtype=bf, device=dev)}
             if rows == S:
                 ws["qkv"] = torch.empty((B * S, 3 * D), dtype=bf, device=dev)      # q | k | v, fused projection
+            elif self.exchange == "a2a":
+                W = D // self.world                                                # columns of this rank's heads
+                ws["qkv"] = torch.empty((rows, 3 * D), dtype=bf, device=dev)       # [rows][rank][q | k | v][W]
+                ws["send"] = torch.empty((self.world, rows, 3 * W), dtype=bf, device=dev)
+                ws["recv"] = torch.empty((S, 3 * W), dtype=bf, device=dev)         # all tokens, own heads: q | k | v
+                ws["oh"] = torch.empty((S, W), dtype=bf, device=dev)               # attention output, own heads
+                ws["oback"] = torch.empty((self.world, rows, W), dtype=bf, device=dev)
             else:
                 ws["q"] = torch.empty((rows, D), dtype=bf, device=dev)             # local queries
                 ws["kv"] = torch.empty((S, 2 * D), dtype=bf, device=dev)           # k | v of ALL tokens (all-gathered)
@@ -363,6 +387,23 @@ class HipDiT:
                         N.gemm(Hb, sb["wqkv"], out=QKV)
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
                         N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads, tokens_per_batch=S)
+                    elif self.exchange == "a2a":
+                        # tokens -> heads: project the band, regroup rank-major, one all-to-all; norm + RoPE + attention over all
+                        # S tokens of this rank's heads; heads -> tokens: the second all-to-all, regroup, output projection.
+                        W, hpr = D // world, self.heads // world
+                        QKV, send, recv, Oh, oback = ws["qkv"], ws["send"], ws["recv"], ws["oh"], ws["oback"]
+                        N.gemm(Hb, sb["wqkv"], out=QKV)
+                        N.permute_021(QKV.view(rows, world, 3 * W), out=send)
+                        work = alltoall_rows_(send, recv.view(world, rows, 3 * W), self.pg, async_op=True)
+                        if work is not None:
+                            work.wait()
+                        q, k, v = recv[:, :W], recv[:, W:2 * W], recv[:, 2 * W:]
+                        N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, hpr, tokens_per_batch=S)
+                        N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
+                        work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
+                        if work is not None:
+                            work.wait()
+                        N.permute_021(oback, out=O.view(rows, world, W))
                     else:
                         # local projections; K|V land directly in this rank's band of the gather buffer.  K|V first, so the
                         # exchange (RCCL's own stream) overlaps the Q projection + q-norm; wait() orders attention after it.
@@ -378,7 +419,9 @@ class HipDiT:
                         if work is not None:
                             work.wait()
                         k, v = KV[:, :D], KV[:, D:]
-                    if B == 1:
+                    if world > 1 and self.exchange == "a2a":
+                        pass
+                    elif B == 1:
                         N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
                     else:
                         Q3 = QKV.view(B, S, 3 * D)

@@ -25,6 +25,7 @@ SIGNATURES = {
     "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "drn_ln_modulate": [_P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
     "drn_bcast_add": [_P, _P, _L, _L, _L, _P],
+    "drn_permute_021": [_P, _P, _L, _L, _L, _P],
     "drn_rmsnorm": [_P, _P, _P, _L, _L, _F, _P],
     "drn_qk_norm_rope": [_P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _L, _L, _F, _P],
     "drn_attention_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
@@ -210,6 +211,18 @@ def bcast_add(x, vec, rows_per_batch=None):
     _check(load_library().drn_bcast_add(_ptr(x), _ptr(vec), rows, D, rows_per_batch if rows_per_batch else max(rows, 1),
                                         _stream()), "drn_bcast_add")
     return x
+
+
+def permute_021(x, out=None):
+    """[A, B, C] -> [B, A, C] (contiguous both sides)."""
+    _bf16(x, out)
+    A, B, C = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty((B, A, C), dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.numel() == x.numel()
+    _check(load_library().drn_permute_021(_ptr(x), _ptr(out), A, B, C, _stream()), "drn_permute_021")
+    return out
 
 
 def rmsnorm(x, w, eps=1e-6):

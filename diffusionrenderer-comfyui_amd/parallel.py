@@ -7,9 +7,15 @@ except self-attention, so the token rows [S, D] are cut into `world` contiguous 
 self-attention block is needed: the all-gather of the post-RMSNorm/RoPE K and V rows.  The bands are
 gathered rank-major, which IS the global token order, so no permutation follows.
 
-xGMI is a full point-to-point mesh (7 links per GPU): an all-gather moves each peer's shard over its own
-link once (S/world * 2D * 2 B per peer: 37.7 MB at S = 18432, world = 8), so it is issued as ONE collective
-per layer on the full [S, 2D] buffer rather than per-head pieces.
+Two exchanges implement that one dependency:
+
+* head <-> token all-to-all (default when `world` divides the head count): after the fused QKV projection of its token
+  band a rank sends every peer the q|k|v columns of THAT peer's heads and receives all S tokens of its own heads;
+  attention then runs over (heads/world) complete heads, and a second all-to-all returns the outputs to token bands.
+  Per layer and rank 7/8 * (3 + 1) * S/world * D * 2 B = 66 MB leave over the 7 xGMI links (9.4 MB per link) - a quarter
+  of the all-gather's traffic, in the pattern a point-to-point mesh serves best (every link busy, one hop).
+* K|V all-gather (fallback, any world that divides S): every rank receives all other bands' K and V rows
+  (S * 2D * 2 B * 7/8 = 264 MB per layer and rank).
 """
 from typing import Optional, Tuple
 
@@ -61,3 +67,15 @@ def allgather_rows(local: torch.Tensor, plan: ShardPlan, group=None) -> torch.Te
     full = torch.empty((plan.S,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(full, local.contiguous(), group=group)
     return full
+
+
+def alltoall_rows_(send: torch.Tensor, recv: torch.Tensor, group=None, async_op: bool = False):
+    """Equal-split all-to-all: send [world, n, C] (slab r goes to rank r) -> recv [world, n, C] (slab r came from rank r)."""
+    assert send.is_contiguous() and recv.is_contiguous() and send.shape == recv.shape
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # test-only path (two ranks sharing one GPU cannot use RCCL): host staging
+        out = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(out, send.cpu(), group=group)
+        recv.copy_(out)
+        return None
+    return dist.all_to_all_single(recv, send, group=group, async_op=async_op)

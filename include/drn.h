@@ -77,6 +77,11 @@ int drn_ln_modulate(void* x, const void* add_vec, const void* shift, const void*
 /* ---- x[rows,D] <- bf16(x + vec[batch,:]) (stand-alone broadcast residual; same arithmetic as above) */
 int drn_bcast_add(void* x, const void* vec, int64_t rows, int64_t D, int64_t rows_per_batch, void* stream);
 
+/* ---- y[b][a][:] = x[a][b][:] for x [A, B, C] bf16 (C % 8 == 0): the regroup either side of the head <-> token all-to-all of
+ * the sequence-parallel self-attention (token-major [rows, ranks, C] <-> rank-major [ranks, rows, C]); pure data movement.
+ * New on this path: the reference has no multi-GPU code. */
+int drn_permute_021(const void* x, void* y, int64_t A, int64_t B, int64_t C, void* stream);
+
 /* ---- RMSNorm over the last dim, fp32 internal: y = bf16(x * rsqrt(mean(x^2)+eps) * w)   CleanGeneralDIT.py:14-33 */
 int drn_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t D, float eps, void* stream);
 

@@ -340,3 +340,11 @@ def test_pick_kv_splits(pkg):
     assert f(1, 32, 4608, 18432) == 4
     assert f(1, 32, 9216, 18432) == 1
     assert f(1, 2, 128, 128) == 1
+
+
+def test_permute_021_bit_exact(pkg, gpu):
+    x = torch.randn(37, 8, 1536, device=gpu).to(torch.bfloat16)
+    y = pkg.native.permute_021(x)
+    assert torch.equal(y, x.permute(1, 0, 2).contiguous())
+    z = pkg.native.permute_021(y)
+    assert torch.equal(z, x)

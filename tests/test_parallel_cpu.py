@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _sharded_forward(orc, O, par, x, t, cond, ci, group):
+def _sharded_forward(orc, O, par, x, t, cond, ci, group, exchange="gather"):
     """DitOracle.forward restated over one token band (mirrors HipDiT.forward's structure)."""
     rank, world = par.group_info(group)
     dt = orc.dtype
@@ -41,7 +41,8 @@ def _sharded_forward(orc, O, par, x, t, cond, ci, group):
     xs = F.linear(plan.band(patches.reshape(S, K)), orc.w("x_embedder.proj.1.weight")).unsqueeze(1)    # [rows,1,D]
     ang = O.rope_angles(Tp, Hp, Wp, orc.dh, orc.w("pos_embedder.seq"), orc.tables_dtype)
     cos, sin = O.rope_cos_sin(ang, orc.tables_dtype)
-    cos, sin = plan.band(cos.to(dt)), plan.band(sin.to(dt))                                            # pos_offset = band start
+    cos_all, sin_all = cos.to(dt), sin.to(dt)
+    cos, sin = plan.band(cos_all), plan.band(sin_all)                                                  # pos_offset = band start
     cs = ctx.permute(1, 0, 2)
     for i in range(orc.L):
         for j, kind in enumerate(orc.kinds):
@@ -54,6 +55,29 @@ def _sharded_forward(orc, O, par, x, t, cond, ci, group):
                 out = orc.mlp(pre + "block.", h)
             elif kind == "ca":
                 out = orc.attention(pre + "block.attn.", h, cs, None, None)
+            elif exchange == "a2a":
+                # HipDiT's head <-> token exchange: rank-major fused projection, all-to-all, norm + RoPE + attention over all
+                # S tokens of this rank's heads, all-to-all back, regroup to token-major head order
+                a = pre + "block.attn."
+                W, hpr, rows = D // world, orc.Hn // world, plan.rows
+                wq, wk, wv = (orc.w(a + f"to_{n}.0.weight") for n in "qkv")
+                wqkv = torch.stack([wq.view(world, W, -1), wk.view(world, W, -1), wv.view(world, W, -1)], 1).reshape(3 * D, -1)
+                qkv = F.linear(h.reshape(rows, D), wqkv)                                    # [rows][rank][q|k|v][W]
+                send = qkv.view(rows, world, 3 * W).permute(1, 0, 2).contiguous()           # drn_permute_021
+                recv = torch.empty_like(send)
+                par.alltoall_rows_(send, recv, group)
+                recv = recv.view(S, 3 * W)
+                q = recv[:, :W].reshape(S, 1, hpr, orc.dh)
+                k = recv[:, W:2 * W].reshape(S, 1, hpr, orc.dh)
+                v = recv[:, 2 * W:].reshape(S, 1, hpr, orc.dh)
+                q = O.apply_rope(O.rms_norm(q, orc.w(a + "to_q.1.weight")), cos_all, sin_all)
+                k = O.apply_rope(O.rms_norm(k, orc.w(a + "to_k.1.weight")), cos_all, sin_all)
+                o = F.scaled_dot_product_attention(q.permute(1, 2, 0, 3), k.permute(1, 2, 0, 3), v.permute(1, 2, 0, 3))
+                oh = o.permute(2, 0, 1, 3).reshape(world, rows, W).contiguous()             # [S, W] seen as per-band slabs
+                back = torch.empty_like(oh)
+                par.alltoall_rows_(oh, back, group)
+                o = back.permute(1, 0, 2).reshape(rows, 1, D)                               # drn_permute_021
+                out = F.linear(o, orc.w(a + "to_out.0.weight"))
             else:
                 a = pre + "block.attn."
                 q = F.linear(h, orc.w(a + "to_q.0.weight")).reshape(plan.rows, 1, orc.Hn, orc.dh)
@@ -102,13 +126,18 @@ def _worker(rank, world, port, q):
         with torch.no_grad():
             full = orc.forward(x, t, cond, ci)
             shard = _sharded_forward(orc, O, par, x, t, cond, ci, dist.group.WORLD)
-        err = ((shard - full).norm() / full.norm()).item()
+            shard2 = _sharded_forward(orc, O, par, x, t, cond, ci, dist.group.WORLD, exchange="a2a")
+        err = max(((shard - full).norm() / full.norm()).item(), ((shard2 - full).norm() / full.norm()).item())
         # helpers on their own
         plan = par.ShardPlan(12, rank, world)
         buf = torch.zeros(12, 3)
         plan.band(buf)[:] = rank + 1
         par.allgather_rows_(buf, plan, dist.group.WORLD)
         ok_gather = bool((buf[:6] == 1).all() and (buf[6:] == 2).all())
+        snd = torch.full((world, 3, 2), float(rank)) + torch.arange(world).view(world, 1, 1) * 10       # slab r -> rank r
+        rcv = torch.empty_like(snd)
+        par.alltoall_rows_(snd, rcv, dist.group.WORLD)
+        ok_gather = ok_gather and all(bool((rcv[r] == r + rank * 10).all()) for r in range(world))
         q.put((rank, err, ok_gather))
     finally:
         dist.destroy_process_group()

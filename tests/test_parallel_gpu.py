@@ -1,7 +1,8 @@
 """The HIP engine's token-band path on real hardware: two ranks (both on the one visible GPU, gloo for the exchange -
 RCCL refuses two ranks on one device) run HipDiT sharded and must reproduce the single-rank HipDiT output.  This
-exercises the split Q / K|V projections into the gather buffer, the RoPE position offset, the K/V all-gather layout and
-the gathered final projection with the real kernels; the RCCL transport itself is exercised by bench.py --gpus N."""
+exercises both exchanges with the real kernels - the head <-> token all-to-all (rank-major fused projection, regroup kernel,
+norm + RoPE after the exchange) and the K|V all-gather (split Q / K|V projections into the gather buffer, RoPE position
+offset) - and the gathered final projection; the RCCL transport itself is exercised by bench.py --gpus N."""
 import os
 import socket
 
@@ -22,9 +23,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange):
     import sys
     sys.path.insert(0, ROOT)
+    os.environ["DRN_SP_EXCHANGE"] = exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -40,6 +42,7 @@ def _worker(rank, world, port, q):
         cond = sw.synth_tensor("pg.c", (1, 16, 2, 16, 16), torch.float32, scale=1.0).to(torch.bfloat16).to(dev)
         single = pkg.dit_engine.HipDiT(net, sd, device=dev)
         sharded = pkg.dit_engine.HipDiT(net, sd, device=dev, process_group=dist.group.WORLD)
+        assert sharded.exchange == exchange
         y1 = single(x, torch.tensor(1.7), cond, 2)
         y2 = sharded(x, torch.tensor(1.7), cond, 2)
         torch.cuda.synchronize()
@@ -48,12 +51,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_hipdit_equals_single_rank(gpu):
+@pytest.mark.parametrize("exchange", ["a2a", "gather"])
+def test_sharded_hipdit_equals_single_rank(gpu, exchange):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
