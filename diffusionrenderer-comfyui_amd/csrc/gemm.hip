@@ -161,19 +161,43 @@ int drn_gemm256_dispatch(const void* A, const void* W, void* C, int64_t M, int64
                          int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
                          void* stream);
 
-static bool use_gemm256(int64_t M, int64_t N) {
-    static int mode = -1;                       // DRN_GEMM256=0 forces the 128x128 kernel (A/B runs)
-    if (mode < 0) {
+// gemm144.hip: 144x256x64 kernel (token bands of sequence parallelism: M = 2304 k)
+int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                         int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
+                         void* stream);
+
+// Tile choice by a wave-quantisation model (measured on MI355X).  Time unit = one 256^2 workgroup owning a CU for the whole
+// K loop.  128^2 workgroups run two per CU at ~1000 vs ~1300 TF/s: a full round of 512 takes ~0.65 units.  A 144x256
+// workgroup does 56 % of the work of a 256^2 one at 0.85-1.0x its rate: DRN_GEMM144_COST = 0.64 units (measured: M = 2304
+// -> 0.79 vs 0.97 ms per DiT block; M = 18432 stays on 256^2).
+// Returns 0: 128^2, 1: 256^2, 2: 144x256.   DRN_GEMM256=0 / DRN_GEMM144=0 switch a kernel off, DRN_GEMM144=2 forces it (A/B runs).
+static int g_force_tile = -1;
+extern "C" void drn_gemm_force_tile(int tile) { g_force_tile = tile; }
+
+static int pick_gemm_tile(int64_t M, int64_t N) {
+    static int mode256 = -1, mode144 = -1;
+    static double cost144 = 0.0;
+    if (mode256 < 0) {
         const char* e = getenv("DRN_GEMM256");
-        mode = (e && e[0] == '0') ? 0 : 1;
+        mode256 = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("DRN_GEMM144");
+        mode144 = e ? atoi(e) : 1;
+        e = getenv("DRN_GEMM144_COST");
+        cost144 = e ? atof(e) : 0.64;
     }
-    if (mode != 1 || M < 256 || N < 256 || N % 256 != 0) return false;
-    // wave-quantisation model (measured on MI355X): a 256^2 workgroup owns a CU for 1 time unit; 128^2 workgroups run two per
-    // CU at ~1000 vs ~1300 TF/s, i.e. a full round of 512 of them takes ~0.65 units
-    const int64_t t256 = ((M + 255) / 256) * (N / 256), t128 = ((M + 127) / 128) * (N / 128);
-    const double c256 = (double)((t256 + 255) / 256), c128 = 0.65 * (double)((t128 + 511) / 512);
-    return c256 <= c128;
+    if (N < 256 || N % 256 != 0) return 0;
+    if (g_force_tile >= 0) return g_force_tile;
+    const int64_t t256 = ((M + 255) / 256) * (N / 256), t128 = ((M + 127) / 128) * (N / 128), t144 = ((M + 143) / 144) * (N / 256);
+    const double c128 = 0.65 * (double)((t128 + 511) / 512);
+    const double c256 = (mode256 == 1 && M >= 256) ? (double)((t256 + 255) / 256) : 1e30;
+    // (below half a round of workgroups the model says nothing: the launch is latency / weight-stream bound)
+    const double c144 = (mode144 >= 1 && M >= 144 && t144 >= 128) ? cost144 * (double)((t144 + 255) / 256) : 1e30;
+    if (mode144 == 2 && M >= 144) return 2;
+    if (c144 < c256 && c144 < c128) return 2;
+    return c256 <= c128 ? 1 : 0;
 }
+
+extern "C" int drn_gemm_tile_choice(int64_t M, int64_t N) { return pick_gemm_tile(M, N); }
 
 extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                              int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
@@ -186,8 +210,11 @@ extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, i
         DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
     if (M == 0) return DRN_OK;
     if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
-    if (use_gemm256(M, N))
+    const int tile = pick_gemm_tile(M, N);
+    if (tile == 1)
         return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
+    if (tile == 2)
+        return drn_gemm144_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
     DRN_CHECK_ARG(tiles < (1ll << 31));
     dim3 grid((unsigned)tiles), block(256);

@@ -22,6 +22,8 @@ SIGNATURES = {
     "drn_abi_version": [],
     "drn_error_string": [_I],
     "drn_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _P],
+    "drn_gemm_tile_choice": [_L, _L],
+    "drn_gemm_force_tile": [_I],
     "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "drn_ln_modulate": [_P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
     "drn_bcast_add": [_P, _P, _L, _L, _L, _P],
@@ -267,9 +269,36 @@ def pick_kv_splits(batch, heads, Sq, Sk) -> int:
     return best
 
 
+def attention_plan(batch, heads, Sq, Sk):
+    """How to cover the (q-block, head) grid with whole rounds of the 256 CUs: a list of (q_begin, q_end, kv_splits).
+
+    One workgroup = 256 queries of one head and owns a CU for its whole key range, so `blocks` workgroups take
+    ceil(blocks / 256) rounds and a fractional last round idles CUs (1152 blocks = 4.5 rounds cost 5).  Plan: the q-blocks
+    that fill whole rounds run unsplit; the remaining q-blocks (< 1 round of workgroups) run as a second launch with their
+    keys cut into chunks (split-KV + combine) so that they, too, fill the CUs.  Costs from pick_kv_splits' measured model."""
+    per_qb = batch * heads
+    nqb = (Sq + 255) // 256
+    blocks = nqb * per_qb
+    n_all = pick_kv_splits(batch, heads, Sq, Sk)
+    cost_all = float(-(-blocks // _NUM_CUS)) if n_all == 1 else -(-(blocks * n_all) // _NUM_CUS) * (1.0 / n_all + 0.04) + 0.06
+    rounds = blocks // _NUM_CUS
+    nqb_main = (rounds * _NUM_CUS) // per_qb
+    if rounds == 0 or nqb_main == 0 or nqb_main == nqb:
+        return [(0, Sq, n_all)]
+    q_cut = nqb_main * 256
+    n_tail = pick_kv_splits(batch, heads, Sq - q_cut, Sk)
+    tail_blocks = (nqb - nqb_main) * per_qb
+    cost_tail = (float(-(-tail_blocks // _NUM_CUS)) if n_tail == 1
+                 else -(-(tail_blocks * n_tail) // _NUM_CUS) * (1.0 / n_tail + 0.04) + 0.06)
+    cost_two = -(-(nqb_main * per_qb) // _NUM_CUS) + cost_tail + 0.02          # + the launch boundary
+    if cost_two < cost_all:
+        return [(0, q_cut, 1), (q_cut, Sq, n_tail)]
+    return [(0, Sq, n_all)]
+
+
 def attention(q, k, v, out=None, heads=None, scale=None, kv_splits=None):
     """q: [B, Sq, H*128], k/v: [B, Sk, H*128] (token-strided views allowed) -> out [B, Sq, H*128].
-    kv_splits: None = automatic (pick_kv_splits), 1 = single pass, n > 1 = split-KV + combine."""
+    kv_splits: None = automatic (attention_plan), 1 = single pass, n > 1 = split-KV + combine."""
     _bf16(q, k, v, out)
     B, Sq, HD = q.shape
     Sk = k.shape[1]
@@ -279,26 +308,28 @@ def attention(q, k, v, out=None, heads=None, scale=None, kv_splits=None):
         out = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q.device)
     if scale is None:
         scale = 1.0 / (128 ** 0.5)
-    ns = pick_kv_splits(B, H, Sq, Sk) if kv_splits is None else int(kv_splits)
+    plan = attention_plan(B, H, Sq, Sk) if kv_splits is None else [(0, Sq, int(kv_splits))]
     t0 = _TIMER.begin("attention") if _TIMER is not None else None
     lib = load_library()
-    if ns > 1:
-        nbytes = lib.drn_attention_splitkv_workspace_bytes(B, H, Sq, ns)
-        key = (q.device, nbytes)
-        ws = _SPLIT_WS.get(key)
-        if ws is None:
-            _SPLIT_WS.clear()
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-            _SPLIT_WS[key] = ws
-        _check(lib.drn_attention_splitkv_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
-                                              q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                                              q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, ns, ws.data_ptr(),
-                                              _stream()), "drn_attention_splitkv_bf16")
-    else:
-        _check(lib.drn_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Sq, Sk,
-                                      q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
-               "drn_attention_bf16")
+    for q0, q1, ns in plan:
+        qs, os_, n = q[:, q0:q1], out[:, q0:q1], q1 - q0
+        if ns > 1:
+            nbytes = lib.drn_attention_splitkv_workspace_bytes(B, H, n, ns)
+            key = (q.device, nbytes)
+            ws = _SPLIT_WS.get(key)
+            if ws is None:
+                _SPLIT_WS.clear()
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+                _SPLIT_WS[key] = ws
+            _check(lib.drn_attention_splitkv_bf16(_ptr(qs), _ptr(k), _ptr(v), _ptr(os_), B, H, n, Sk,
+                                                  q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, ns,
+                                                  ws.data_ptr(), _stream()), "drn_attention_splitkv_bf16")
+        else:
+            _check(lib.drn_attention_bf16(_ptr(qs), _ptr(k), _ptr(v), _ptr(os_), B, H, n, Sk,
+                                          q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                          q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+                   "drn_attention_bf16")
     if t0 is not None:
         _TIMER.end("attention", t0, 4.0 * B * H * Sq * Sk * 128, 2.0 * B * H * 128 * (2 * Sq + 2 * Sk))
     return out

@@ -52,6 +52,12 @@ int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, i
                   const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
                   void* stream);
 
+/* ---- tuning hooks of drn_gemm_bf16 (no reference counterpart): which tile kernel the wave-quantisation model picks for an
+ * [M, N] output (0: 128x128, 1: 256x256, 2: 144x256; N % 256 != 0 always takes 128x128), and a process-wide override for
+ * A/B runs and tests (-1 = automatic). */
+int drn_gemm_tile_choice(int64_t M, int64_t N);
+void drn_gemm_force_tile(int tile);
+
 /* ---- weight-streaming GEMV family (batch-1 vectors: timestep MLP, AdaLN-LoRA, the 1-key cross-attention).
  * For g in [0,groups), b in [0,batch): y[g,b,:] = epi(W[g] . act(x[g,b,:]))   W[g]: [N,K] bf16
  *   y = bf16(acc); if add: y = bf16(y + add[g,b,n]); if mul: y = bf16(mul[g,b,n] * y)

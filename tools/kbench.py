@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--S", type=int, default=18432)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--splits", type=int, default=1, help="attention: split-KV chunks (drn_attention_splitkv_bf16)")
+    ap.add_argument("--tiles", default="-1", help="gemm: comma list of forced tile kernels (-1 auto, 0 128^2, 1 256^2, 2 144x256)")
     ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
     args = ap.parse_args()
     pkg = load_package()
@@ -73,12 +74,16 @@ def main():
             R = rnd(S, Nn) if epi == 2 else None
             gate = rnd(1, Nn) if epi == 2 else None
 
-            def run_gemm(lib, A=A, Wt=Wt, C=C, R=R, gate=gate, Nn=Nn, K=K, epi=epi):
+            tiles = [int(t) for t in args.tiles.split(",")]
+            for tile in tiles:
+              def run_gemm(lib, A=A, Wt=Wt, C=C, R=R, gate=gate, Nn=Nn, K=K, epi=epi, tile=tile):
+                lib.drn_gemm_force_tile(tile)
                 rc = lib.drn_gemm_bf16(A.data_ptr(), Wt.data_ptr(), C.data_ptr(), S, Nn, K, K, K, Nn, epi,
                                        gate.data_ptr() if gate is not None else None,
                                        R.data_ptr() if R is not None else None, Nn, S, st)
+                lib.drn_gemm_force_tile(-1)
                 assert rc == 0, rc
-            cases.append((f"gemm {nm} [{S}x{K}]x[{Nn}x{K}]", run_gemm, 2.0 * S * Nn * K))
+              cases.append((f"gemm {nm} [{S}x{K}]x[{Nn}x{K}] tile {tile}", run_gemm, 2.0 * S * Nn * K))
     for name, fn, fl in cases:
         times = [[] for _ in handles]
         for lib in handles:

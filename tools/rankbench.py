@@ -1,0 +1,74 @@
+"""Per-rank compute of the sequence-parallel DiT forward, measured on ONE GPU: the exchanges are replaced by no-ops, so the
+kernels run on rank 0's shapes (token band of S/world rows, heads/world heads after the all-to-all); the peers' data is
+faked by device copies of this rank's own slabs (same value distribution; the copies cost ~0.02 ms per exchange).
+What it shows: the compute floor of `bench.py --gpus N` and which kernels lose efficiency at the per-rank shapes.
+
+    python tools/rankbench.py --world 8 [--exchange a2a|gather] [--steps 4]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--exchange", default="a2a")
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=57)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--blocks", type=int, default=28)
+    args = ap.parse_args()
+    os.environ["DRN_SP_EXCHANGE"] = args.exchange
+    pkg = load_package()
+    eng, N = pkg.dit_engine, pkg.native
+    world = args.world
+    eng.group_info = lambda pg=None: (0, world)
+
+    def fake_alltoall(send, recv, pg=None, async_op=False):
+        recv.copy_(send)
+
+    def fake_allgather(full, plan, pg=None, async_op=False):
+        if full.shape[0] == plan.S and plan.world > 1:
+            full.view(plan.world, plan.rows, -1)[1:].copy_(plan.band(full).unsqueeze(0).expand(plan.world - 1, -1, -1))
+
+    eng.alltoall_rows_ = fake_alltoall
+    eng.allgather_rows_ = fake_allgather
+    dev = torch.device("cuda", 0)
+    cfg = pkg.diffusion_renderer_config.get_inverse_renderer_config(args.height, args.width, args.frames)
+    net = dict(cfg["net"], num_blocks=args.blocks)
+    sw = pkg.synthetic_weights
+    dit = eng.HipDiT(net, sw.synth_state_dict(net, torch.bfloat16, device=dev), device=dev, process_group=object())
+    F_, h, w = (args.frames - 1) // 8 + 1, args.height // 8, args.width // 8
+    x = sw.synth_tensor("rb.x", (1, 16, F_, h, w), torch.float32, device=dev, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor("rb.c", (1, 16, F_, h, w), torch.float32, device=dev, scale=1.0).to(torch.bfloat16)
+    sig = [80.0 * 0.8 ** i for i in range(args.steps + 1)]
+    dit.prepare_timesteps(sig)
+    dit(x, sig[0], cond, 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in sig[1:]:
+        dit(x, s_, cond, 3)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    timer = N.KernelTimer(sample_every=3)
+    N.set_timer(timer)
+    dit(x, sig[1], cond, 3)
+    torch.cuda.synchronize()
+    N.set_timer(None)
+    print(f"world={world} exchange={dit.exchange}: {ms:.2f} ms per forward on this rank's shapes (no communication)")
+    for name, d in timer.summary().items():
+        n = d["launches_seen"]
+        print(f"  {name:10s} {n:4d} launches  avg {d['ms_avg']:.3f} ms  -> {d['ms_avg'] * n:7.2f} ms per forward, "
+              f"{d['flops'] / d['ms_total'] / 1e9:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
