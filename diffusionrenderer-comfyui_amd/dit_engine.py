@@ -117,10 +117,11 @@ class HipDiT:
                     a = q + "block.attn."
                     wq, wk, wv = g(a + "to_q.0.weight"), g(a + "to_k.0.weight"), g(a + "to_v.0.weight")
                     if self.exchange == "a2a":
-                        # output columns grouped by the rank that will own the heads: [rank][q | k | v][heads/world * 128]
+                        # K|V output columns grouped by the rank that will own the heads: [rank][k | v][heads/world * 128];
+                        # q rows are rank-major as they are (a rank's heads are contiguous).  Kept as [q ; k|v] row blocks.
                         W = self.D // self.world
-                        wqkv = torch.stack([wq.view(self.world, W, -1), wk.view(self.world, W, -1),
-                                            wv.view(self.world, W, -1)], 1).reshape(3 * self.D, -1).contiguous()
+                        wkv = torch.stack([wk.view(self.world, W, -1), wv.view(self.world, W, -1)], 1).reshape(2 * self.D, -1)
+                        wqkv = torch.cat([wq, wkv], 0).contiguous()
                     else:
                         wqkv = torch.cat([wq, wk, wv], 0).contiguous()
                     subs.append({"kind": "fa", "wqkv": wqkv,
@@ -225,9 +226,12 @@ class HipDiT:
                 ws["qkv"] = torch.empty((B * S, 3 * D), dtype=bf, device=dev)      # q | k | v, fused projection
             elif self.exchange == "a2a":
                 W = D // self.world                                                # columns of this rank's heads
-                ws["qkv"] = torch.empty((rows, 3 * D), dtype=bf, device=dev)       # [rows][rank][q | k | v][W]
-                ws["send"] = torch.empty((self.world, rows, 3 * W), dtype=bf, device=dev)
-                ws["recv"] = torch.empty((S, 3 * W), dtype=bf, device=dev)         # all tokens, own heads: q | k | v
+                ws["qb"] = torch.empty((rows, D), dtype=bf, device=dev)            # band projections: [rows][rank][W]
+                ws["kvb"] = torch.empty((rows, 2 * D), dtype=bf, device=dev)       #                   [rows][rank][k | v][W]
+                ws["sq"] = torch.empty((self.world, rows, W), dtype=bf, device=dev)        # send slabs, rank-major
+                ws["skv"] = torch.empty((self.world, rows, 2 * W), dtype=bf, device=dev)
+                ws["rq"] = torch.empty((S, W), dtype=bf, device=dev)               # all tokens, own heads
+                ws["rkv"] = torch.empty((S, 2 * W), dtype=bf, device=dev)
                 ws["oh"] = torch.empty((S, W), dtype=bf, device=dev)               # attention output, own heads
                 ws["oback"] = torch.empty((self.world, rows, W), dtype=bf, device=dev)
             else:
@@ -388,18 +392,25 @@ class HipDiT:
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
                         N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads, tokens_per_batch=S)
                     elif self.exchange == "a2a":
-                        # tokens -> heads: project the band, regroup rank-major, one all-to-all; norm + RoPE + attention over all
-                        # S tokens of this rank's heads; heads -> tokens: the second all-to-all, regroup, output projection.
+                        # tokens -> heads: project the band, regroup rank-major, all-to-all; norm + RoPE + attention over all S
+                        # tokens of this rank's heads; heads -> tokens: all-to-all back, regroup, output projection.
+                        # K|V go first so their exchange (RCCL's stream, 2/3 of the bytes) overlaps the Q projection.
                         W, hpr = D // world, self.heads // world
-                        QKV, send, recv, Oh, oback = ws["qkv"], ws["send"], ws["recv"], ws["oh"], ws["oback"]
-                        N.gemm(Hb, sb["wqkv"], out=QKV)
-                        N.permute_021(QKV.view(rows, world, 3 * W), out=send)
-                        work = alltoall_rows_(send, recv.view(world, rows, 3 * W), self.pg, async_op=True)
-                        if work is not None:
-                            work.wait()
-                        q, k, v = recv[:, :W], recv[:, W:2 * W], recv[:, 2 * W:]
-                        N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, hpr, tokens_per_batch=S)
-                        N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
+                        Oh, oback, rq, rkv = ws["oh"], ws["oback"], ws["rq"], ws["rkv"]
+                        N.gemm(Hb, sb["wqkv"][D:], out=ws["kvb"])
+                        N.permute_021(ws["kvb"].view(rows, world, 2 * W), out=ws["skv"])
+                        work_kv = alltoall_rows_(ws["skv"], rkv.view(world, rows, 2 * W), self.pg, async_op=True)
+                        N.gemm(Hb, sb["wqkv"][:D], out=ws["qb"])
+                        N.permute_021(ws["qb"].view(rows, world, W), out=ws["sq"])
+                        work_q = alltoall_rows_(ws["sq"], rq.view(world, rows, W), self.pg, async_op=True)
+                        if work_kv is not None:
+                            work_kv.wait()
+                        k, v = rkv[:, :W], rkv[:, W:]
+                        N.qk_norm_rope(None, k, None, sb["kn"], cos, sin, hpr, tokens_per_batch=S)
+                        if work_q is not None:
+                            work_q.wait()
+                        N.qk_norm_rope(rq, None, sb["qn"], None, cos, sin, hpr, tokens_per_batch=S)
+                        N.attention(rq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
                         work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
                         if work is not None:
                             work.wait()

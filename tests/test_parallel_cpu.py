@@ -61,15 +61,18 @@ def _sharded_forward(orc, O, par, x, t, cond, ci, group, exchange="gather"):
                 a = pre + "block.attn."
                 W, hpr, rows = D // world, orc.Hn // world, plan.rows
                 wq, wk, wv = (orc.w(a + f"to_{n}.0.weight") for n in "qkv")
-                wqkv = torch.stack([wq.view(world, W, -1), wk.view(world, W, -1), wv.view(world, W, -1)], 1).reshape(3 * D, -1)
-                qkv = F.linear(h.reshape(rows, D), wqkv)                                    # [rows][rank][q|k|v][W]
-                send = qkv.view(rows, world, 3 * W).permute(1, 0, 2).contiguous()           # drn_permute_021
-                recv = torch.empty_like(send)
-                par.alltoall_rows_(send, recv, group)
-                recv = recv.view(S, 3 * W)
-                q = recv[:, :W].reshape(S, 1, hpr, orc.dh)
-                k = recv[:, W:2 * W].reshape(S, 1, hpr, orc.dh)
-                v = recv[:, 2 * W:].reshape(S, 1, hpr, orc.dh)
+                wkv = torch.stack([wk.view(world, W, -1), wv.view(world, W, -1)], 1).reshape(2 * D, -1)
+                hb = h.reshape(rows, D)
+                skv = F.linear(hb, wkv).view(rows, world, 2 * W).permute(1, 0, 2).contiguous()     # [rows][rank][k|v][W] -> rank-major
+                rkv = torch.empty_like(skv)
+                par.alltoall_rows_(skv, rkv, group)                                               # exchange 1 (K|V first)
+                sq = F.linear(hb, wq).view(rows, world, W).permute(1, 0, 2).contiguous()
+                rq = torch.empty_like(sq)
+                par.alltoall_rows_(sq, rq, group)                                                 # exchange 2 (Q)
+                rkv, rq = rkv.view(S, 2 * W), rq.view(S, W)
+                q = rq.reshape(S, 1, hpr, orc.dh)
+                k = rkv[:, :W].reshape(S, 1, hpr, orc.dh)
+                v = rkv[:, W:].reshape(S, 1, hpr, orc.dh)
                 q = O.apply_rope(O.rms_norm(q, orc.w(a + "to_q.1.weight")), cos_all, sin_all)
                 k = O.apply_rope(O.rms_norm(k, orc.w(a + "to_k.1.weight")), cos_all, sin_all)
                 o = F.scaled_dot_product_attention(q.permute(1, 2, 0, 3), k.permute(1, 2, 0, 3), v.permute(1, 2, 0, 3))
