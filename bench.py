@@ -237,7 +237,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"inverse pass, {args.frames}f x {args.height} x {args.width} clip: EDM Euler step = 1 DiT "
                                    f"forward (D=4096, {args.blocks} blocks, 32 heads) over S={S} tokens, guidance 0",
-                       "latent": [16, F_, h, w], "tokens": S, "parallelism": f"sp{world} (token bands, K/V all-gather)",
+                       "latent": [16, F_, h, w], "tokens": S, "parallelism": (f"sp{world} (token bands; self-attention exchange: "
+                                       + {"none": "none", "a2a": "head<->token all-to-all", "gather": "K/V all-gather"}[model.net.exchange] + ")"),
                        "weights": "random-init (hash generator), 7.2e9 params bf16"},
             "dit_tflops_reference_equivalent": round(fl_faithful / (ms * 1e-3) / 1e12, 1),
             "dit_tflops_executed": round(fl_exec / (ms * 1e-3) / 1e12, 1),
