@@ -115,7 +115,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:          # under torch.distributed.run (also its 1-rank rehearsal)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
@@ -252,7 +252,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, S)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -75,7 +75,12 @@ class HipDiT:
             raise ValueError("DRN_SP_EXCHANGE must be auto, a2a or gather")
         if mode == "a2a" and self.heads % world:
             raise ValueError(f"head all-to-all needs the world size ({world}) to divide the head count ({self.heads})")
-        self.exchange = "none" if world == 1 else ("gather" if mode == "gather" or self.heads % world else "a2a")
+        if process_group is None:
+            self.exchange = "none"
+        elif mode == "auto":
+            self.exchange = "none" if world == 1 else ("gather" if self.heads % world else "a2a")
+        else:
+            self.exchange = mode               # explicit: also honoured by a 1-rank group (exercises the RCCL calls on one GPU)
         self.world = world
         self._load(state_dict, prefix)
         self._rope_cache = {}
@@ -222,7 +227,7 @@ class HipDiT:
                   "o": torch.empty((n, D), dtype=bf, device=dev),
                   "u": torch.empty((n, int(D * self.net["mlp_ratio"])), dtype=bf, device=dev),
                   "y": torch.empty((B * S, self.w_final.shape[0]), dtype=bf, device=dev)}
-            if rows == S:
+            if self.exchange == "none":
                 ws["qkv"] = torch.empty((B * S, 3 * D), dtype=bf, device=dev)      # q | k | v, fused projection
             elif self.exchange == "a2a":
                 W = D // self.world                                                # columns of this rank's heads
@@ -288,7 +293,7 @@ class HipDiT:
         Tp, Hp, Wp = F_ // self.pt, h // self.ps, w // self.ps
         S = Tp * Hp * Wp
         rank, world = group_info(self.pg) if self.pg is not None else (0, 1)
-        if B > 1 and world > 1:
+        if B > 1 and self.exchange != "none":
             # token-band sharding is per clip; a sharded job walks the clips (each still spans every rank)
             return torch.cat([self.forward(x[b:b + 1], sigma, cond[b:b + 1], cis[b]) for b in range(B)], 0)
         plan = ShardPlan(S, rank, world)
@@ -311,7 +316,7 @@ class HipDiT:
         """Replay the ~300 launches of a small-shape forward as one hipGraph (DRN_GRAPHS=1).  Measured: no gain - even at
         S = 256 the eager launches run ahead of the GPU once nothing synchronises inside the denoising loop."""
         import os
-        return (world == 1 and S <= 4096 and self.trace is None and N._TIMER is None
+        return (self.exchange == "none" and S <= 4096 and self.trace is None and N._TIMER is None
                 and os.environ.get("DRN_GRAPHS", "0") == "1")     # opt-in: measured null on MI355X (13.64 vs 13.66 ms at S=256)
 
     def _graph_forward(self, x, cond, mod, modf, addvec, Tp, Hp, Wp):
@@ -353,7 +358,7 @@ class HipDiT:
         """The kernel sequence of one forward (all shapes / pointers fixed for a given input shape -> capturable)."""
         D = self.D
         S, rows, world = plan.S, plan.rows, plan.world
-        B = x.shape[0]                                           # B > 1 only with world == 1 (rows == S)
+        B = x.shape[0]                                           # B > 1 only without an exchange (rows == S)
         cos, sin = self.rope(Tp, Hp, Wp)
         ws = self._workspace(S, rows, B)
         X, Hb, O, U, Y = ws["x"], ws["h"], ws["o"], ws["u"], ws["y"]
@@ -386,7 +391,7 @@ class HipDiT:
                 N.ln_modulate(X, shift, scale, out=Hb, add_vec=pending, rows_per_batch=rows)
                 pending = None
                 if sb["kind"] == "fa":
-                    if world == 1:
+                    if self.exchange == "none":
                         QKV = ws["qkv"]
                         N.gemm(Hb, sb["wqkv"], out=QKV)
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
@@ -430,7 +435,7 @@ class HipDiT:
                         if work is not None:
                             work.wait()
                         k, v = KV[:, :D], KV[:, D:]
-                    if world > 1 and self.exchange == "a2a":
+                    if self.exchange == "a2a":
                         pass
                     elif B == 1:
                         N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)

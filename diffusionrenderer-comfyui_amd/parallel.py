@@ -45,9 +45,13 @@ def group_info(group=None) -> Tuple[int, int]:
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+# tests set this to run the collectives of a 1-rank group too (RCCL call path on a single GPU)
+SINGLE_RANK_COLLECTIVES = False
+
+
 def allgather_rows_(full: torch.Tensor, plan: ShardPlan, group=None, async_op: bool = False):
     """In-place all-gather: `full` is [S, C] contiguous, this rank's band already holds its rows."""
-    if plan.world == 1:
+    if plan.world == 1 and not (SINGLE_RANK_COLLECTIVES and group is not None):
         return None
     assert full.is_contiguous() and full.shape[0] == plan.S
     if dist.get_backend(group) == "gloo" and full.is_cuda:

@@ -68,3 +68,49 @@ def test_sharded_hipdit_equals_single_rank(gpu, exchange):
         # (the wave-wide deferred-rescale decision could differ if bands regrouped rows; 64-row bands keep the 32-row waves)
         assert same or maxdiff < 2e-2, f"rank {rank}: sharded != single (max |diff| {maxdiff})"
         print(f"rank {rank}: identical={same} max|diff|={maxdiff}")
+
+
+def _rccl_worker(port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        pkg.parallel.SINGLE_RANK_COLLECTIVES = True
+        net = tiny_net(pkg, 256, 2, 2)
+        sw = pkg.synthetic_weights
+        sd = sw.synth_state_dict(net, torch.bfloat16, device=dev)
+        x = sw.synth_tensor("pg.x", (1, 16, 2, 16, 16), torch.float32, scale=2.0).to(torch.bfloat16).to(dev)
+        cond = sw.synth_tensor("pg.c", (1, 16, 2, 16, 16), torch.float32, scale=1.0).to(torch.bfloat16).to(dev)
+        y1 = pkg.dit_engine.HipDiT(net, sd, device=dev)(x, torch.tensor(1.7), cond, 2)
+        res = {}
+        for mode in ("a2a", "gather"):
+            os.environ["DRN_SP_EXCHANGE"] = mode
+            eng = pkg.dit_engine.HipDiT(net, sd, device=dev, process_group=dist.group.WORLD)
+            assert eng.exchange == mode
+            for _ in range(3):                                   # repeated: buffer reuse across async exchanges
+                y2 = eng(x, torch.tensor(1.7), cond, 2)
+            torch.cuda.synchronize()
+            res[mode] = bool(torch.equal(y1, y2))
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_paths_over_rccl_single_rank(gpu):
+    """The real transport: a 1-rank RCCL group drives both exchange paths (async all_to_all_single / all_gather_into_tensor on
+    device buffers, work.wait() stream ordering, workspace reuse over repeated forwards) and must not change a bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    res = q.get(timeout=10)
+    assert res == {"a2a": True, "gather": True}, res
