@@ -159,7 +159,8 @@ def main():
     # HIP-event pairs around every 7th GEMM / attention launch (7 is coprime with the 4-GEMM-per-block pattern, so all four
     # shapes are sampled evenly); bracketing every launch would add ~10 ms of queue time per step
     # (small shapes replay the forward as one hipGraph, where per-launch events do not apply: no roofline there)
-    timer = N.KernelTimer(sample_every=7) if (rank == 0 and S > 4096 and not os.environ.get("DRN_NO_TIMER")) else None
+    # (sharded runs: every 29th launch, the event pairs sit on rank 0 only and would skew its step against the other ranks)
+    timer = N.KernelTimer(sample_every=7 if world == 1 else 29) if (rank == 0 and S > 4096 and not os.environ.get("DRN_NO_TIMER")) else None
     N.set_timer(timer)
     t0 = time.perf_counter()
     # inside the timed region: the timed steps' AdaLN vectors, batched as generate_samples_from_batch does before its loop

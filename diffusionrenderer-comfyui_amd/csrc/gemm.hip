@@ -174,7 +174,7 @@ int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64
 static int g_force_tile = -1;
 extern "C" void drn_gemm_force_tile(int tile) { g_force_tile = tile; }
 
-static int pick_gemm_tile(int64_t M, int64_t N) {
+static int pick_gemm_tile(int64_t M, int64_t N, double* cost_out = nullptr) {
     static int mode256 = -1, mode144 = -1;
     static double cost144 = 0.0;
     if (mode256 < 0) {
@@ -185,6 +185,7 @@ static int pick_gemm_tile(int64_t M, int64_t N) {
         e = getenv("DRN_GEMM144_COST");
         cost144 = e ? atof(e) : 0.64;
     }
+    if (cost_out) *cost_out = 1e30;
     if (N < 256 || N % 256 != 0) return 0;
     if (g_force_tile >= 0) return g_force_tile;
     const int64_t t256 = ((M + 255) / 256) * (N / 256), t128 = ((M + 127) / 128) * (N / 128), t144 = ((M + 143) / 144) * (N / 256);
@@ -193,8 +194,9 @@ static int pick_gemm_tile(int64_t M, int64_t N) {
     // (below half a round of workgroups the model says nothing: the launch is latency / weight-stream bound)
     const double c144 = (mode144 >= 1 && M >= 144 && t144 >= 128) ? cost144 * (double)((t144 + 255) / 256) : 1e30;
     if (mode144 == 2 && M >= 144) return 2;
-    if (c144 < c256 && c144 < c128) return 2;
-    return c256 <= c128 ? 1 : 0;
+    const int best = (c144 < c256 && c144 < c128) ? 2 : (c256 <= c128 ? 1 : 0);
+    if (cost_out) *cost_out = best == 2 ? c144 : (best == 1 ? c256 : c128);
+    return best;
 }
 
 extern "C" int drn_gemm_tile_choice(int64_t M, int64_t N) { return pick_gemm_tile(M, N); }
@@ -210,7 +212,38 @@ extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, i
         DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
     if (M == 0) return DRN_OK;
     if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
-    const int tile = pick_gemm_tile(M, N);
+    double cost_all = 0.0;
+    const int tile = pick_gemm_tile(M, N, &cost_all);
+    // A fractional last round of 256^2 workgroups idles CUs (72 x 16 tiles = 4.5 rounds cost 5).  Rows are independent, so the
+    // tile rows that fill whole rounds run as one launch and the remaining rows as a second one with the tile that suits
+    // them (DRN_GEMM_TAIL=0 switches this off).
+    static int tail_mode = -1;
+    if (tail_mode < 0) {
+        const char* e = getenv("DRN_GEMM_TAIL");
+        tail_mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (tile == 1 && tail_mode == 1 && g_force_tile < 0) {
+        const int64_t tm = (M + 255) / 256, tn = N / 256;
+        const int64_t rounds = tm * tn / 256, rem = tm * tn % 256;
+        const int64_t tm_main = rounds * 256 / tn;
+        const int64_t M_main = tm_main * 256;
+        const bool gate_ok = epilogue != DRN_EPI_GATE_RES || rows_per_batch >= M || M_main % rows_per_batch == 0;
+        if (rounds >= 1 && rem != 0 && tm_main >= 1 && tm_main < tm && gate_ok) {
+            double cost_tail = 0.0;
+            pick_gemm_tile(M - M_main, N, &cost_tail);
+            const double cost_split = (double)((tm_main * tn + 255) / 256) + cost_tail + 0.02;
+            if (cost_split < cost_all - 0.05) {
+                const int rc = drn_gemm256_dispatch(A, W, C, M_main, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr,
+                                                    rows_per_batch, stream);
+                if (rc != DRN_OK) return rc;
+                const bf16_t* gate_t = (const bf16_t*)gate;
+                if (epilogue == DRN_EPI_GATE_RES && rows_per_batch < M) gate_t += (M_main / rows_per_batch) * N;
+                return drn_gemm_bf16((const bf16_t*)A + M_main * lda, W, (bf16_t*)C + M_main * ldc, M - M_main, N, K, lda, ldw, ldc,
+                                     epilogue, gate_t, residual ? (const bf16_t*)residual + M_main * ldr : nullptr, ldr,
+                                     rows_per_batch, stream);
+            }
+        }
+    }
     if (tile == 1)
         return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
     if (tile == 2)

@@ -344,6 +344,25 @@ def test_gemm144_identity_and_choice(pkg, gpu):
     assert lib.drn_gemm_tile_choice(256, 4096) == 0 and lib.drn_gemm_tile_choice(2304, 128) == 0
 
 
+@pytest.mark.parametrize("rpb", [4608 + 100, 2048])
+def test_gemm_tail_split_auto(pkg, gpu, rpb):
+    """Automatic dispatch at a shape with a fractional last round (18 x 16 tiles of 256^2 = 1 round + 32): 16 tile rows run
+    as 256^2 workgroups, the last 512 (+100 ragged) rows as a second launch; per-batch gates must follow the row offset."""
+    M, N, K = 4608 + 100, 4096, 128
+    a, w = rnd((M, K), gpu, seed=80), rnd((N, K), gpu, K ** -0.5, seed=81)
+    nb = -(-M // rpb)
+    x, gate = rnd((M, N), gpu, seed=82), rnd((nb, N), gpu, 0.5, seed=83)
+    lin = (a.float() @ w.float().t()).to(BF)
+    g_rows = gate[torch.arange(M, device=gpu) // rpb]
+    ref = x + g_rows * lin
+    out = x.clone()
+    pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out, rows_per_batch=rpb)
+    ok, msg = ulp_diff_ok(out, ref, max_ulp=2, frac_exact=0.97, mag=torch.maximum(x.abs(), (g_rows * lin).abs()))
+    assert ok, msg
+    ok, msg = ulp_diff_ok(pkg.native.gemm(a, w), lin, max_ulp=1)
+    assert ok, msg
+
+
 def test_gemm256_identity_asymmetric(pkg, gpu):
     M = K = 1024
     N = 256
