@@ -119,6 +119,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
+        # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step
+        probe = torch.zeros(world * 1024, dtype=torch.bfloat16, device=dev)
+        dist.all_to_all_single(torch.empty_like(probe), probe)
+        dist.all_gather_into_tensor(torch.empty(world * 1024, dtype=torch.bfloat16, device=dev), probe[:1024].contiguous())
+        torch.cuda.synchronize()
 
     pkg = load_package()
     N = pkg.native

@@ -114,3 +114,29 @@ def test_batched_forward_equals_per_clip_forwards(pkg, gpu):
         dit(x, torch.tensor([1.0, 2.0, 3.0]), cond, cis)          # one sigma per batch
     with pytest.raises(ValueError):
         dit(x, torch.tensor(1.0), cond, [0, 1])                   # one index per clip
+
+
+def test_full_size_block_cfg3_matches_oracle(pkg, gpu):
+    """BASELINE config 3 shapes (latent 8 x 72 x 128 -> S = 18 432 tokens, D = 4096, 32 heads), ONE transformer block: the
+    256^2 GEMM, the whole-round attention launch and every elementwise kernel at the sizes the bench runs, against the CPU
+    oracle on the same seeded inputs (bf16 oracle = what the reference computes, fp32 oracle = the exact answer)."""
+    import time
+    from oracle import dit_oracle as O
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    net = tiny_net(pkg, 4096, 1, 32)
+    sw = pkg.synthetic_weights
+    sd = sw.synth_state_dict(net, torch.bfloat16)
+    F_, h, w = 8, 72, 128
+    x = sw.synth_tensor("full.x", (1, 16, F_, h, w), torch.float32, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor("full.c", (1, 16, F_, h, w), torch.float32, scale=1.0).to(torch.bfloat16)
+    t, ci = torch.tensor(3.0), torch.full((1, 1), 3, dtype=torch.long)
+    dit = pkg.dit_engine.HipDiT(net, {k: v.to(gpu) for k, v in sd.items()}, device=gpu)
+    y = dit(x.to(gpu), t, cond.to(gpu), ci).cpu()
+    t0 = time.time()
+    with torch.no_grad():
+        ref16 = O.DitOracle(sd, net, dtype=torch.bfloat16).forward(x, t, cond, ci)
+        exact = O.DitOracle(sd, net, dtype=torch.float32, tables_dtype=torch.bfloat16).forward(x, t, cond, ci)
+    e_ref, e_hip, d = rel_l2(ref16, exact), rel_l2(y, exact), rel_l2(y, ref16)
+    print(f"cfg3 one block: e_ref={e_ref:.3e} e_hip={e_hip:.3e} hip-vs-ref16={d:.3e} (oracle {time.time() - t0:.0f}s)")
+    assert e_hip <= max(1.5 * e_ref, 1e-3), (e_hip, e_ref)
+    assert d <= max(2.0 * e_ref, 2e-3), (d, e_ref)
