@@ -191,8 +191,9 @@ static int pick_gemm_tile(int64_t M, int64_t N, double* cost_out = nullptr) {
     const int64_t t256 = ((M + 255) / 256) * (N / 256), t128 = ((M + 127) / 128) * (N / 128), t144 = ((M + 143) / 144) * (N / 256);
     const double c128 = 0.65 * (double)((t128 + 511) / 512);
     const double c256 = (mode256 == 1 && M >= 256) ? (double)((t256 + 255) / 256) : 1e30;
-    // (below half a round of workgroups the model says nothing: the launch is latency / weight-stream bound)
-    const double c144 = (mode144 >= 1 && M >= 144 && t144 >= 128) ? cost144 * (double)((t144 + 255) / 256) : 1e30;
+    // (well below one round of workgroups the model says nothing - measured at M = 1024, N = 4096: 128 workgroups of 144x256
+    //  550 TF/s vs 256 of 128^2 655 TF/s - so the 144-row tile needs at least 3/4 of a round)
+    const double c144 = (mode144 >= 1 && M >= 144 && t144 >= 192) ? cost144 * (double)((t144 + 255) / 256) : 1e30;
     if (mode144 == 2 && M >= 144) return 2;
     const int best = (c144 < c256 && c144 < c128) ? 2 : (c256 <= c128 ? 1 : 0);
     if (cost_out) *cost_out = best == 2 ? c144 : (best == 1 ? c256 : c128);
