@@ -183,20 +183,41 @@ class CleanDiffusionRendererModel:
         if latent_shape is None:
             raise ValueError(f"Could not determine latent shape from keys {condition_keys}.")
         ref = data_batch[self.input_data_key]
-        parts = []
         mask_shape = (latent_shape[0], 1, *latent_shape[2:])
-        for cond_key in condition_keys:
-            actual = cond_key if cond_key in data_batch else ("rgb" if "rgb" in data_batch and cond_key == "image" else None)
+        actual_keys = [k if k in data_batch else ("rgb" if "rgb" in data_batch and k == "image" else None)
+                       for k in condition_keys]
+        states = self._encode_conditions([data_batch[k] for k in actual_keys if k is not None])
+        parts = []
+        for actual in actual_keys:
             if actual is None:
                 parts.append(torch.zeros(latent_shape, dtype=ref.dtype, device=ref.device))
                 if self.append_condition_mask:
                     parts.append(torch.zeros(mask_shape, dtype=ref.dtype, device=ref.device))
             else:
-                state = self._encode_cached(data_batch[actual])
+                state = states.pop(0)
                 parts.append(state)
                 if self.append_condition_mask:
                     parts.append(torch.ones(mask_shape, dtype=state.dtype, device=state.device))
         return torch.cat(parts, dim=1)
+
+    def _encode_conditions(self, tensors: list) -> list:
+        """Tokenizer encodes of the condition maps.  One rank: one after the other (cached per tensor).  Several ranks: the
+        maps are independent, so rank r encodes maps r, r + world, ... and the 2.4 MB latents are all-gathered - the forward
+        renderer's 8 encodes ('other free parallelism') cost one encode per rank on an 8-GPU node."""
+        from .parallel import allgather_stack, group_info
+        rank, world = group_info(self.process_group) if self.process_group is not None else (0, 1)
+        n = len(tensors)
+        if world == 1 or n < 2:
+            return [self._encode_cached(t) for t in tensors]
+        per = -(-n // world)
+        f = self.vae.spatial_compression_factor
+        B, _, T, H, W = tensors[0].shape
+        mine = torch.zeros((per, B, self.vae.latent_ch, self.vae.get_latent_num_frames(T), H // f, W // f),
+                           dtype=self.dtype, device=self.device)          # zero slots pad ranks with fewer maps
+        for j, i in enumerate(range(rank, n, world)):
+            mine[j] = self._encode_cached(tensors[i])
+        allv = allgather_stack(mine, self.process_group)                  # [world, per, B, C, F, h, w]
+        return [allv[i % world, i // world] for i in range(n)]
 
     def _get_conditions(self, data_batch: Dict, is_negative_prompt: bool = False):
         for key in ("rgb", "basecolor", "normal", "depth", "roughness", "metallic", "image"):

@@ -83,3 +83,18 @@ def alltoall_rows_(send: torch.Tensor, recv: torch.Tensor, group=None, async_op:
         recv.copy_(out)
         return None
     return dist.all_to_all_single(recv, send, group=group, async_op=async_op)
+
+
+def allgather_stack(local: torch.Tensor, group=None) -> torch.Tensor:
+    """local [k, ...] on every rank (same k) -> [world, k, ...] in rank order."""
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        parts = [torch.empty_like(local) for _ in range(world)]       # test-only path, see allgather_rows_
+        dist.all_gather(parts, local, group=group)
+        for r, p in enumerate(parts):
+            out[r].copy_(p)
+        return out
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out
