@@ -17,6 +17,8 @@
 // Softmax in fp32 (exp2 with the scale folded in), P rounded to bf16 for the PV MFMA, row sum from the fp32 P.
 #include "drn_common.h"
 
+// EXPV: ablation builds behind the stall budget quoted in DESIGN.md (1: no barrier, 2: no K/V staging, 4: no exp) -
+// timing only, results are wrong; the shipped library is built with 0.
 #ifndef EXPV
 #define EXPV 0
 #endif
