@@ -81,3 +81,20 @@ def test_model_strict_state_dict(pkg):
         m.load_state_dict({"net.bogus": torch.zeros(1)}, strict=True)
     with pytest.raises(RuntimeError, match="weights not loaded"):
         m.generate_samples_from_batch({}, state_shape=(16, 1, 4, 4))
+
+
+def test_state_dict_names_equal_reference_manifest(pkg):
+    """the names / shapes load_state_dict(strict=True) expects are those of the reference model's own full-size
+    state dict (tests/golden/state_dict_manifest.json, written by tools/make_goldens.py from the reference on the meta device)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    man = json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))
+    M = pkg.model_diffusion_renderer.CleanDiffusionRendererModel
+    cm = pkg.diffusion_renderer_config
+    for kind, cfg in (("inverse", cm.get_inverse_renderer_config()), ("forward", cm.get_forward_renderer_config())):
+        cfg["model_type"] = kind
+        mine = {k: list(v) for k, v in M(cfg, device="cpu").expected_state_dict_shapes().items()}
+        assert mine == man[kind], kind
+    assert man["inverse"]["net.x_embedder.proj.1.weight"] == [4096, 132]
+    assert man["forward"]["net.x_embedder.proj.1.weight"] == [4096, 612]

@@ -268,6 +268,22 @@ def pretrained_vae_case(ref):
     return out, meta
 
 
+def manifest_case(ref):
+    """Names and shapes of the reference model's full-size state dict (28 blocks, D = 4096), built on the meta device: what
+    a real checkpoint holds, i.e. what CleanDiffusionRendererModel.load_state_dict(strict=True) must accept."""
+    import json
+    out = {}
+    for kind in ("inverse", "forward"):
+        cfg = ref.config.get_forward_renderer_config() if kind == "forward" else ref.config.get_inverse_renderer_config()
+        with torch.device("meta"):
+            m = ref.model.CleanDiffusionRendererModel(cfg)
+        out[kind] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    path = os.path.join(GOLD, "state_dict_manifest.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
 def save(name, tensors, meta):
     os.makedirs(GOLD, exist_ok=True)
     path = os.path.join(GOLD, name)
@@ -287,6 +303,8 @@ def main():
     def want(n):
         return todo is None or n in todo
 
+    if want("manifest"):
+        manifest_case(ref)
     if want("sched"):
         save("scheduler.safetensors", *scheduler_and_post_case(ref))
     if want("pv"):
