@@ -56,14 +56,22 @@ def main():
     t0 = time.perf_counter()
     for s_ in sig[1:]:
         dit(x, s_, cond, 3)
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to ENQUEUE a forward (must stay below the GPU time)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dit(x, sig[1], cond, 3)
+    one_ms = (time.perf_counter() - t0) * 1e3                      # empty queue: pure host cost of one forward
+    torch.cuda.synchronize()
+    print(f"host cost of one forward on an empty queue: {one_ms:.2f} ms")
     timer = N.KernelTimer(sample_every=3)
     N.set_timer(timer)
     dit(x, sig[1], cond, 3)
     torch.cuda.synchronize()
     N.set_timer(None)
-    print(f"world={world} exchange={dit.exchange}: {ms:.2f} ms per forward on this rank's shapes (no communication)")
+    print(f"world={world} exchange={dit.exchange}: {ms:.2f} ms per forward on this rank's shapes (no communication); "
+          f"host enqueue {host_ms:.2f} ms per forward")
     for name, d in timer.summary().items():
         n = d["launches_seen"]
         print(f"  {name:10s} {n:4d} launches  avg {d['ms_avg']:.3f} ms  -> {d['ms_avg'] * n:7.2f} ms per forward, "
