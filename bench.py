@@ -119,11 +119,23 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
-        # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step
+        # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step; if this build of RCCL
+        # cannot run the all-to-all, fall back to the all-gather exchange instead of losing the run
         probe = torch.zeros(world * 1024, dtype=torch.bfloat16, device=dev)
-        dist.all_to_all_single(torch.empty_like(probe), probe)
         dist.all_gather_into_tensor(torch.empty(world * 1024, dtype=torch.bfloat16, device=dev), probe[:1024].contiguous())
         torch.cuda.synchronize()
+        if os.environ.get("DRN_SP_EXCHANGE", "auto") != "gather":
+            ok = torch.ones(1, device=dev)
+            try:
+                dist.all_to_all_single(torch.empty_like(probe), probe)
+                torch.cuda.synchronize()
+            except Exception as e:                                       # noqa: BLE001 - any transport error means "use gather"
+                print(f"[bench] rank {rank}: all_to_all_single failed ({type(e).__name__}: {e}); using the all-gather exchange",
+                      file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # every rank must take the same path
+            if ok.item() == 0:
+                os.environ["DRN_SP_EXCHANGE"] = "gather"
 
     pkg = load_package()
     N = pkg.native
