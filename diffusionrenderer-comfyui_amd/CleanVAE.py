@@ -35,9 +35,21 @@ def _ceil(x, m):
 
 
 class HipCosmosTokenizer:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict = None, device=None):
+    """The tokenizer on HIP kernels.  With a process group of `world` ranks every frame is cut into `world` bands of image rows
+    (SURVEY.md 8f N3): causal temporal convs, 1x1x1 convs, Haar patching, resampling and the temporal attention are local to
+    a band; the spatial 3x3 convs read one neighbour row per side (exchanged into the 1-pixel halo that already surrounds
+    every activation), the per-frame GroupNorm sums its statistics over the ranks, and the mid block's spatial attention
+    gathers K and V.  The latent / the decoded video are gathered at the end, so callers see the single-GPU interface."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict = None, device=None, process_group=None):
         self.cfg = dict(cfg or COSMOS_CV8x8x8)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.pg = process_group
+        self.rank, self.world = (0, 1)
+        if process_group is not None:
+            from .parallel import group_info
+            self.rank, self.world = group_info(process_group)
+        self._bands = 1                       # > 1 while a band-sharded encode / decode is running
         N.load_library()
         self.ps = self.cfg["patch_size"]
         if self.ps != 4 or self.cfg.get("patch_type", "haar") != "haar":
@@ -73,6 +85,8 @@ class HipCosmosTokenizer:
     def conv(self, name, x: CL, stride=(1, 1, 1), pad=0, t_off=None, residual=None, out_halo=1, out_dims=None) -> CL:
         w, k, co, cip = self.w[name]
         assert x.C == cip, (name, x.C, cip)
+        if self._bands > 1 and k[1] == 3:
+            self._exchange_rows(x)                                    # neighbour rows into the halo before a spatial conv
         stored = _ceil(co, 64) if co % 64 else co                     # 16-channel latents live in 64-channel buffers
         return V.conv3d(x, w, self.b[name], co, k, stride, pad, t_off, residual=residual, out_halo=out_halo,
                         out_dims=out_dims, out_channels_stored=stored)
@@ -81,7 +95,25 @@ class HipCosmosTokenizer:
         return self.conv(name + ".conv_t", self.conv(name + ".conv_s", x, pad=1), residual=residual)
 
     def norm(self, name, x: CL, silu: bool) -> CL:
-        return V.groupnorm_silu(x, self.g[name + ".norm"], self.b[name + ".norm"], silu)
+        if self._bands == 1:
+            return V.groupnorm_silu(x, self.g[name + ".norm"], self.b[name + ".norm"], silu)
+        from .parallel import allgather_stack
+        part = allgather_stack(V.groupnorm_stats(x), self.pg)                         # [world, T, 64, 2]
+        part = part.permute(1, 0, 2, 3).reshape(x.T, self.world * 64, 2).contiguous()
+        count = float(x.H * self.world) * float(x.W) * float(x.C)
+        return V.groupnorm_apply(x, part, count, self.g[name + ".norm"], self.b[name + ".norm"], silu)
+
+    def _exchange_rows(self, x: CL) -> None:
+        """Top / bottom halo rows of this band <- last / first interior row of the neighbour bands (image border: stay zero).
+        One small all-gather of the two edge rows of every rank (T x (W+2) x C each); the neighbours' rows are picked out."""
+        from .parallel import allgather_stack
+        assert x.halo == 1
+        edges = torch.stack([x.t[:, 1], x.t[:, x.H]], 0)                              # [2, T, W+2, C]
+        allv = allgather_stack(edges, self.pg)                                         # [world, 2, T, W+2, C]
+        if self.rank > 0:
+            x.t[:, 0].copy_(allv[self.rank - 1, 1])
+        if self.rank + 1 < self.world:
+            x.t[:, x.H + 1].copy_(allv[self.rank + 1, 0])
 
     def resnet(self, name, x: CL) -> CL:
         res = self.conv(name + ".conv_shortcut", x) if (name + ".conv_shortcut") in self.w else x
@@ -96,13 +128,18 @@ class HipCosmosTokenizer:
         if temporal:
             o = V.temporal_attention(q, k, v, scale)
         else:
-            P = H * W
-            kp = _ceil(P, 64)
+            if self._bands > 1:                                       # queries of this band against the whole frame's keys
+                from .parallel import allgather_stack
+                kv = allgather_stack(torch.stack([k, v], 0), self.pg)                  # [world, 2, T, H*W, C]
+                k = kv[:, 0].permute(1, 0, 2, 3).reshape(T, self.world * H * W, C)     # bands in rank order = row order
+                v = kv[:, 1].permute(1, 0, 2, 3).reshape(T, self.world * H * W, C)
+            P, Pk = H * W, k.shape[1]
+            kp = _ceil(Pk, 64)
             o = torch.empty((T, P, C), dtype=BF, device=self.device)
             for f in range(T):                                        # one head of dim C per frame
-                s = V.dense_gemm(q[f], k[f], out_f32=True, alpha=scale)
-                p = V.softmax_rows(s, P, kp)
-                V.dense_gemm(p, V.transpose(v[f], kp), out=o[f])
+                s = V.dense_gemm(q[f], k[f].contiguous(), out_f32=True, alpha=scale)
+                p = V.softmax_rows(s, Pk, kp)
+                V.dense_gemm(p, V.transpose(v[f].contiguous(), kp), out=o[f])
         oc = CL(T, H, W, C, 0, self.device, tensor=o.view(T, H, W, C))
         return self.conv(name + ".to_out.0", oc, residual=x)
 
@@ -135,14 +172,19 @@ class HipCosmosTokenizer:
 
     # ------------------------------------------------------------------ encoder / decoder
     @torch.no_grad()
-    def encode(self, video: torch.Tensor) -> torch.Tensor:
-        """[1,3,T,H,W] -> [1,16,F,H/8,W/8]  (AutoencoderKLCosmos.encode(x).latent_dist.sample(): identity posterior)."""
+    def encode(self, video: torch.Tensor, bands: int = None) -> torch.Tensor:
+        """[1,3,T,H,W] -> [1,16,F,H/8,W/8]  (AutoencoderKLCosmos.encode(x).latent_dist.sample(): identity posterior).
+        bands: None = one band of rows per rank of the process group (a collective call), 1 = this rank alone."""
         B, C, T, H, W = video.shape
         if B != 1:
-            return torch.cat([self.encode(video[i:i + 1]) for i in range(B)], 0)
+            return torch.cat([self.encode(video[i:i + 1], bands) for i in range(B)], 0)
         if (T - 1) % 8 != 0 or H % 8 != 0 or W % 8 != 0:
             raise ValueError(f"CV8x8x8 tokenizer needs T = 8k+1 frames and H, W multiples of 8, got {(T, H, W)}")
         cfg = self.cfg
+        self._bands = self.world if (bands is None and self.world > 1 and (H // 8) % self.world == 0) else 1
+        if self._bands > 1:                                           # this rank's band of image rows
+            Hb = H // self._bands
+            video = video[:, :, :, self.rank * Hb:(self.rank + 1) * Hb]
         h = V.haar_patch(video[0].to(device=self.device, dtype=BF).contiguous())
         self._rec("patch", h)
         h = self.proj("encoder.conv_in", h)
@@ -159,15 +201,31 @@ class HipCosmosTokenizer:
         self._rec("mid", h)
         h = self.proj("encoder.conv_out", self.norm("encoder.norm_out", h, True))
         h = self.conv("quant_conv", h)
-        return V.cl_to_planar(h, cfg["latent_channels"]).unsqueeze(0)
+        z = V.cl_to_planar(h, cfg["latent_channels"])
+        if self._bands > 1:
+            z = self._gather_rows(z)
+            self._bands = 1
+        return z.unsqueeze(0)
+
+    def _gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """[C, T, H_band, W] on every rank -> [C, T, H, W] (bands in rank order)."""
+        from .parallel import allgather_stack
+        allv = allgather_stack(t.contiguous(), self.pg)                               # [world, C, T, Hb, W]
+        C_, T_, Hb, W_ = t.shape
+        return allv.permute(1, 2, 0, 3, 4).reshape(C_, T_, self.world * Hb, W_).contiguous()
 
     @torch.no_grad()
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
-        """[1,16,F,h,w] -> [1,3,8(F-1)+1,8h,8w]  (AutoencoderKLCosmos.decode(z).sample)."""
+    def decode(self, z: torch.Tensor, bands: int = None) -> torch.Tensor:
+        """[1,16,F,h,w] -> [1,3,8(F-1)+1,8h,8w]  (AutoencoderKLCosmos.decode(z).sample).  bands: as in encode."""
         B = z.shape[0]
         if B != 1:
-            return torch.cat([self.decode(z[i:i + 1]) for i in range(B)], 0)
+            return torch.cat([self.decode(z[i:i + 1], bands) for i in range(B)], 0)
         cfg = self.cfg
+        hl = z.shape[3]
+        self._bands = self.world if (bands is None and self.world > 1 and hl % self.world == 0) else 1
+        if self._bands > 1:
+            hb = hl // self._bands
+            z = z[:, :, :, self.rank * hb:(self.rank + 1) * hb]
         h = V.planar_to_cl(z[0].to(device=self.device, dtype=BF).contiguous(), 64)
         h = self.conv("post_quant_conv", h)
         h = self.proj("decoder.conv_in", h)
@@ -184,7 +242,11 @@ class HipCosmosTokenizer:
             self._rec(f"up{i}", h)
         h = self.proj("decoder.conv_out", self.norm("decoder.norm_out", h, True))
         self._rec("dec.conv_out", h)
-        return V.haar_unpatch(h, cfg["out_channels"]).unsqueeze(0)
+        video = V.haar_unpatch(h, cfg["out_channels"])
+        if self._bands > 1:
+            video = self._gather_rows(video)
+            self._bands = 1
+        return video.unsqueeze(0)
 
 
 class _Config(dict):
@@ -194,7 +256,8 @@ class _Config(dict):
 class CleanVAE:
     """Drop-in for the reference's CleanVAE (CleanVAE.py:9-67)."""
 
-    def __init__(self, model_path: str = None, state_dict: Dict[str, torch.Tensor] = None, config: dict = None, device=None):
+    def __init__(self, model_path: str = None, state_dict: Dict[str, torch.Tensor] = None, config: dict = None, device=None,
+                 process_group=None):
         cfg = dict(COSMOS_CV8x8x8)
         if model_path is not None:
             cpath = os.path.join(model_path, "config.json")
@@ -215,7 +278,7 @@ class CleanVAE:
         if state_dict is None:
             raise ValueError("CleanVAE needs a model_path or a state_dict")
         self.config = _Config(cfg)
-        self.model = HipCosmosTokenizer(state_dict, cfg, device=device)
+        self.model = HipCosmosTokenizer(state_dict, cfg, device=device, process_group=process_group)
         self.spatial_compression_factor = cfg["spatial_compression_ratio"]
         self.latent_ch = cfg["latent_channels"]
         self.temporal_compression_factor = 8
@@ -231,16 +294,16 @@ class CleanVAE:
         return (num_latent_frames - 1) * self.temporal_compression_factor + 1
 
     @torch.no_grad()
-    def encode(self, state_5d: torch.Tensor) -> torch.Tensor:
+    def encode(self, state_5d: torch.Tensor, bands: int = None) -> torch.Tensor:
         if state_5d.ndim != 5:
             raise ValueError(f"CleanVAE expects a 5D input (B, C, T, H, W), but got {state_5d.shape}")
-        return self.model.encode(state_5d)
+        return self.model.encode(state_5d, bands)
 
     @torch.no_grad()
-    def decode(self, latent_5d: torch.Tensor) -> torch.Tensor:
+    def decode(self, latent_5d: torch.Tensor, bands: int = None) -> torch.Tensor:
         if latent_5d.ndim != 5:
             raise ValueError(f"CleanVAE expects a 5D latent (B, C, T, H, W), but got {latent_5d.shape}")
-        return self.model.decode(latent_5d)
+        return self.model.decode(latent_5d, bands)
 
     def to(self, device):
         return self          # weights were placed on the GPU at load; the HIP path has no CPU mode

@@ -6,48 +6,56 @@
 #include "drn_common.h"
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
-// stats: per frame sum / sum of squares over the whole stored frame (halo is zero, so it does not contribute)
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+// stats: per frame sum / sum of squares over the whole stored frame (halo is zero, so it does not contribute).
+// Accumulated in fp64: the sums are then independent (to ~1e-16) of how the elements are split over threads, blocks and -
+// when a frame is cut into row bands over several GPUs - ranks, so mean / rstd come out the same fp32 numbers either way.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ part,
                                                        int64_t frame_elems, int nblk) {
     const int f = blockIdx.y;
     const bf16_t* xf = x + (int64_t)f * frame_elems;
     const int64_t nch = frame_elems / 8;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nch; i += (int64_t)nblk * 256) {
         float v[8];
         unpack8(*reinterpret_cast<const uint4*>(xf + i * 8), v);
+        float s8 = 0.f, q8 = 0.f;                 // 8 bf16 values: their fp32 sum of squares is exact enough to be order-free
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            s += v[j];
-            q += v[j] * v[j];
+            s8 += v[j];
+            q8 += v[j] * v[j];
         }
+        s += (double)s8;
+        q += (double)q8;
     }
-    __shared__ float sh[2][4];
-    s = wave_sum(s);
-    q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) {
-        sh[0][threadIdx.x >> 6] = s;
-        sh[1][threadIdx.x >> 6] = q;
-    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
     __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + st];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        part[((int64_t)f * nblk + blockIdx.x) * 2 + 0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-        part[((int64_t)f * nblk + blockIdx.x) * 2 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        part[((int64_t)f * nblk + blockIdx.x) * 2 + 0] = sh[0][0];
+        part[((int64_t)f * nblk + blockIdx.x) * 2 + 1] = sh[1][0];
     }
 }
 
 // apply: y = [silu](bf16((x - mean) * rstd * gamma + beta)) on the interior; the output halo is left untouched (zero)
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ part,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const double* __restrict__ part,
                                                        const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                                        bf16_t* __restrict__ y, int H, int W, int C, int halo, int nblk,
-                                                       float eps, int silu) {
+                                                       float eps, int silu, float cnt) {
     const int f = blockIdx.y;
-    float s = 0.f, q = 0.f;
+    double sd = 0.0, qd = 0.0;
     for (int i = 0; i < nblk; ++i) {
-        s += part[((int64_t)f * nblk + i) * 2 + 0];
-        q += part[((int64_t)f * nblk + i) * 2 + 1];
+        sd += part[((int64_t)f * nblk + i) * 2 + 0];
+        qd += part[((int64_t)f * nblk + i) * 2 + 1];
     }
-    const float cnt = (float)H * (float)W * (float)C;
+    const float s = (float)sd, q = (float)qd;
     const float mean = s / cnt;
     const float var = fmaxf(q / cnt - mean * mean, 0.f);
     const float rstd = 1.0f / sqrtf(var + eps);
@@ -81,15 +89,37 @@ extern "C" int drn_groupnorm_silu(const void* x, const void* gamma, const void* 
     DRN_CHECK_ARG(frames <= 65535);
     const int64_t frame_elems = (int64_t)(H + 2 * halo) * (W + 2 * halo) * C;
     hipStream_t st = (hipStream_t)stream;
-    gn_stats_kernel<<<dim3(GN_NBLK, frames), dim3(256), 0, st>>>((const bf16_t*)x, (float*)workspace, frame_elems, GN_NBLK);
+    gn_stats_kernel<<<dim3(GN_NBLK, frames), dim3(256), 0, st>>>((const bf16_t*)x, (double*)workspace, frame_elems, GN_NBLK);
     int64_t blocks = ((int64_t)H * W * (C / 8) + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    gn_apply_kernel<<<dim3((unsigned)blocks, frames), dim3(256), 0, st>>>((const bf16_t*)x, (const float*)workspace,
+    gn_apply_kernel<<<dim3((unsigned)blocks, frames), dim3(256), 0, st>>>((const bf16_t*)x, (const double*)workspace,
                                                                           (const bf16_t*)gamma, (const bf16_t*)beta,
-                                                                          (bf16_t*)y, H, W, C, halo, GN_NBLK, eps, silu);
+                                                                          (bf16_t*)y, H, W, C, halo, GN_NBLK, eps, silu,
+                                                                          (float)H * (float)W * (float)C);
     return drn_launch_status();
 }
-extern "C" int64_t drn_groupnorm_workspace_bytes(int frames) { return (int64_t)frames * GN_NBLK * 2 * sizeof(float); }
+
+// the two halves on their own, for a frame that is spread over several GPUs (row bands): every rank sums its band, the
+// partial sums of all ranks are gathered, and every rank normalises its band with the whole frame's statistics
+extern "C" int drn_groupnorm_stats(const void* x, void* part, int frames, int H, int W, int C, int halo, void* stream) {
+    DRN_CHECK_ARG(x && part && frames > 0 && frames <= 65535 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (halo == 0 || halo == 1));
+    const int64_t frame_elems = (int64_t)(H + 2 * halo) * (W + 2 * halo) * C;
+    gn_stats_kernel<<<dim3(GN_NBLK, frames), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)x, (double*)part, frame_elems, GN_NBLK);
+    return drn_launch_status();
+}
+
+extern "C" int drn_groupnorm_apply(const void* x, const void* part, int nparts, float count, const void* gamma, const void* beta,
+                                   void* y, int frames, int H, int W, int C, int halo, float eps, int silu, void* stream) {
+    DRN_CHECK_ARG(x && part && gamma && beta && y && nparts > 0 && count > 0.f && frames > 0 && frames <= 65535);
+    DRN_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && (halo == 0 || halo == 1));
+    int64_t blocks = ((int64_t)H * W * (C / 8) + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    gn_apply_kernel<<<dim3((unsigned)blocks, frames), dim3(256), 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, (const double*)part, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, H, W, C, halo, nparts, eps,
+        silu, count);
+    return drn_launch_status();
+}
+extern "C" int64_t drn_groupnorm_workspace_bytes(int frames) { return (int64_t)frames * GN_NBLK * 2 * sizeof(double); }
 
 // ------------------------------------------------------------------------------------------------ Haar
 #define HW_ 0.70703125f          // bf16(0.7071067811865476): the wavelet taps are cast to the activation dtype

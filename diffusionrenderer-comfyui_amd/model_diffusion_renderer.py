@@ -139,12 +139,12 @@ class CleanDiffusionRendererModel:
         return {"device": self.device, "dtype": self.dtype}
 
     # ---- tokenizer seam (reference :138-156)
-    def encode(self, x: Tensor) -> Tensor:
+    def encode(self, x: Tensor, **vae_kwargs) -> Tensor:
         if self.vae is None:
             raise RuntimeError("VAE not initialized in model.")
         if x.ndim != 5:
             raise ValueError(f"Model encode expects a 5D tensor (B,C,T,H,W), but got {x.ndim}D.")
-        return self.vae.encode(x) * self.scheduler.sigma_data
+        return self.vae.encode(x, **vae_kwargs) * self.scheduler.sigma_data
 
     def decode(self, x: Tensor) -> Tensor:
         if self.vae is None:
@@ -153,14 +153,14 @@ class CleanDiffusionRendererModel:
             raise ValueError(f"Model decode expects a 5D latent (B,C,T,H,W), but got {x.ndim}D.")
         return self.vae.decode(x / self.scheduler.sigma_data)
 
-    def _encode_cached(self, x: Tensor) -> Tensor:
+    def _encode_cached(self, x: Tensor, **vae_kwargs) -> Tensor:
         """encode(x) with a small identity cache: the inverse node runs 5 G-buffer passes over
         one clip and the reference re-encodes it every pass (model_diffusion_renderer.py:191); same tensor -> same latent."""
         key = (x.data_ptr(), tuple(x.shape), x._version, x.dtype, id(self.vae))
         hit = self._enc_cache.get(key)
         if hit is not None and hit[0] is x:
             return hit[1]
-        latent = self.encode(x).contiguous()
+        latent = self.encode(x, **vae_kwargs).contiguous()
         if len(self._enc_cache) >= 16:
             self._enc_cache.clear()
         self._enc_cache[key] = (x, latent)
@@ -214,8 +214,10 @@ class CleanDiffusionRendererModel:
         B, _, T, H, W = tensors[0].shape
         mine = torch.zeros((per, B, self.vae.latent_ch, self.vae.get_latent_num_frames(T), H // f, W // f),
                            dtype=self.dtype, device=self.device)          # zero slots pad ranks with fewer maps
+        # (a tokenizer that owns a process group would cut every map into row bands - a collective; here each rank works alone)
+        alone = {"bands": 1} if getattr(getattr(self.vae, "model", None), "world", 1) > 1 else {}
         for j, i in enumerate(range(rank, n, world)):
-            mine[j] = self._encode_cached(tensors[i])
+            mine[j] = self._encode_cached(tensors[i], **alone)
         allv = allgather_stack(mine, self.process_group)                  # [world, per, B, C, F, h, w]
         return [allv[i % world, i // world] for i in range(n)]
 

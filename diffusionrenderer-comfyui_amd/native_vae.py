@@ -12,6 +12,8 @@ N.SIGNATURES.update({
                          _L, _L, _I, _F, _P],
     "drn_groupnorm_silu": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "drn_groupnorm_workspace_bytes": [_I],
+    "drn_groupnorm_stats": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "drn_groupnorm_apply": [_P, _P, _I, _F, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "drn_haar_patch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "drn_haar_unpatch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "drn_resample": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -108,6 +110,24 @@ def groupnorm_silu(x: CL, gamma, beta, silu=True, out: CL = None, eps=1e-6):
         _GN_WS[key] = ws
     N._check(lib.drn_groupnorm_silu(x.t.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.t.data_ptr(), ws.data_ptr(),
                                     x.T, x.H, x.W, x.C, x.halo, eps, 1 if silu else 0, N._stream()), "drn_groupnorm_silu")
+    return out
+
+
+def groupnorm_stats(x: CL) -> torch.Tensor:
+    """Partial sums of this rank's rows: [T, 64, 2] fp64 (sum, sum of squares); the halo of x must be zero."""
+    part = torch.empty((x.T, 64, 2), dtype=torch.float64, device=x.t.device)
+    N._check(N.load_library().drn_groupnorm_stats(x.t.data_ptr(), part.data_ptr(), x.T, x.H, x.W, x.C, x.halo, N._stream()),
+             "drn_groupnorm_stats")
+    return part
+
+
+def groupnorm_apply(x: CL, part: torch.Tensor, count: float, gamma, beta, silu=True, eps=1e-6) -> CL:
+    """Normalise this rank's rows with the statistics of the whole frame: part [T, nparts, 2] fp64, count elements per frame."""
+    assert part.dtype == torch.float64 and part.is_contiguous() and part.shape[0] == x.T and part.shape[2] == 2
+    out = CL(x.T, x.H, x.W, x.C, x.halo, x.t.device)
+    N._check(N.load_library().drn_groupnorm_apply(x.t.data_ptr(), part.data_ptr(), part.shape[1], float(count), gamma.data_ptr(),
+                                                  beta.data_ptr(), out.t.data_ptr(), x.T, x.H, x.W, x.C, x.halo, eps,
+                                                  1 if silu else 0, N._stream()), "drn_groupnorm_apply")
     return out
 
 

@@ -166,6 +166,13 @@ int drn_conv3d_igemm(const void* x, const void* w, const void* bias, void* y, co
 int drn_groupnorm_silu(const void* x, const void* gamma, const void* beta, void* y, void* workspace,
                        int frames, int H, int W, int C, int halo, float eps, int silu, void* stream);
 int64_t drn_groupnorm_workspace_bytes(int frames);
+/* the same normalisation in two steps, for frames whose rows are spread over several GPUs: per-rank
+ * partial sums part[frames][64][2] as fp64 (sum, sum of squares over the stored band; the halo rows must still be zero; fp64 makes
+ * the totals independent of the split), then - after the ranks' partials were gathered to part[frames][nparts][2] - the normalisation of this rank's band with
+ * count = H_total * W * C elements per frame. */
+int drn_groupnorm_stats(const void* x, void* part, int frames, int H, int W, int C, int halo, void* stream);
+int drn_groupnorm_apply(const void* x, const void* part, int nparts, float count, const void* gamma, const void* beta,
+                        void* y, int frames, int H, int W, int C, int halo, float eps, int silu, void* stream);
 
 /* ---- 2-level 3-D Haar patching (CosmosPatchEmbed3d, patch 4): video [Cin][T][H][W] planar ->
  * [ (T+3)/4 ][H/4+2*halo][W/4+2*halo][64*Cin]; and its inverse (CosmosUnpatcher3d) -> [C][4*Tp-3][4*Hq][4*Wq]. */

@@ -167,3 +167,54 @@ def test_condition_encodes_spread_over_ranks(gpu):
     for rank, same_lat, same_x0, shape in sorted(q.get(timeout=10) for _ in range(world)):
         assert shape == (1, 8 * 17, 2, 4, 4)
         assert same_lat and same_x0, f"rank {rank}: {same_lat} {same_x0}"
+
+
+def _tok_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        dev = torch.device("cuda:0")
+        sw = pkg.synthetic_weights
+        sd = sw.synth_vae_state_dict(device=dev)
+        one = pkg.CleanVAE.CleanVAE(state_dict=sd, device=dev)
+        banded = pkg.CleanVAE.CleanVAE(state_dict=sd, device=dev, process_group=dist.group.WORLD)
+        T, H, W = 9, 64, 96
+        clip = sw.synth_tensor("tok.clip", (1, 3, T, H, W), torch.float32).to(torch.bfloat16).to(dev)
+        z1, z2 = one.encode(clip), banded.encode(clip)
+        v1, v2 = one.decode(z1), banded.decode(z1)
+        z3 = banded.encode(clip, bands=1)                       # explicit single-rank call on a banded tokenizer
+        torch.cuda.synchronize()
+
+        def cmp(a, b):
+            a, b = a.float(), b.float()
+            return (float((a - b).norm() / b.norm()), float((a == b).float().mean()), tuple(a.shape))
+        q.put((rank, cmp(z2, z1), cmp(v2, v1), bool(torch.equal(z3, z1))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tokenizer_row_bands_equal_single_rank(gpu):
+    """every frame cut into 2 bands of image rows (halo-row exchange before the spatial convs, GroupNorm
+    statistics summed over the ranks, K/V gathered for the mid-block attention).  Same arithmetic per element; the GroupNorm
+    sums are accumulated in fp64, which makes them independent of the split - so the result is the single-rank one, bit for bit."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tok_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank, (ez, same_z, shz), (ev, same_v, shv), alone_ok in sorted(q.get(timeout=10) for _ in range(world)):
+        print(f"rank {rank}: latent rel-L2 {ez:.2e} ({same_z:.3f} identical), video rel-L2 {ev:.2e} ({same_v:.3f} identical)")
+        assert shz == (1, 16, 2, 8, 12) and shv == (1, 3, 9, 64, 96)
+        assert alone_ok
+        assert ez == 0.0 and ev == 0.0 and same_z == 1.0 and same_v == 1.0

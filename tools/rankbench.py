@@ -16,6 +16,31 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package  # noqa: E402
 
 
+def tokenizer_band(pkg, args, dev):
+    """One rank's row band of the tokenizer (rank 1: both neighbours exist); gathers are faked by device copies."""
+    world = args.world
+    sw = pkg.synthetic_weights
+    pkg.parallel.allgather_stack = lambda local, group=None: local.unsqueeze(0).expand(world, *local.shape).contiguous()
+    vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=dev), device=dev)
+    clip = sw.synth_tensor("rb.rgb", (1, 3, args.frames, args.height, args.width), torch.float32, device=dev).to(torch.bfloat16)
+    res = {}
+    for w_ in (1, world):
+        vae.model.rank, vae.model.world, vae.model.pg = (min(1, w_ - 1), w_, None)
+        z = vae.encode(clip)
+        vae.decode(z)
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        z = vae.encode(clip)
+        e[1].record()
+        vae.decode(z)
+        e[2].record()
+        torch.cuda.synchronize()
+        res[w_] = (e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]))
+    print(f"tokenizer {args.frames}f x {args.height} x {args.width}: one GPU encode {res[1][0]:.2f} ms decode {res[1][1]:.2f} ms; "
+          f"one band of {world}: encode {res[world][0]:.2f} ms decode {res[world][1]:.2f} ms (exchanges faked by device copies)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
@@ -25,6 +50,7 @@ def main():
     ap.add_argument("--height", type=int, default=576)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--blocks", type=int, default=28)
+    ap.add_argument("--tokenizer", action="store_true", help="time this rank's band of the tokenizer instead of the DiT")
     args = ap.parse_args()
     os.environ["DRN_SP_EXCHANGE"] = args.exchange
     pkg = load_package()
@@ -42,6 +68,8 @@ def main():
     eng.alltoall_rows_ = fake_alltoall
     eng.allgather_rows_ = fake_allgather
     dev = torch.device("cuda", 0)
+    if args.tokenizer:
+        return tokenizer_band(pkg, args, dev)
     cfg = pkg.diffusion_renderer_config.get_inverse_renderer_config(args.height, args.width, args.frames)
     net = dict(cfg["net"], num_blocks=args.blocks)
     sw = pkg.synthetic_weights
