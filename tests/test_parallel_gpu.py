@@ -131,29 +131,30 @@ def _cond_worker(rank, world, port, q):
         net = tiny_net(pkg, 256, 1, 2, forward=True)
         cfg = dict(cfgm.get_forward_renderer_config(), net=net, model_type="forward")
         sd = sw.synth_state_dict(net, torch.bfloat16, device=dev)
-        vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=dev), device=dev)
+        vsd = sw.synth_vae_state_dict(device=dev)
         outs = []
         for pg in (None, dist.group.WORLD):
             model = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(dict(cfg), device=dev, process_group=pg)
             model.load_state_dict(sd, strict=True)
-            model.vae = vae
+            model.vae = pkg.CleanVAE.CleanVAE(state_dict=vsd, device=dev, process_group=pg)   # row-band tokenizer when sharded
             batch = {k: sw.synth_tensor("cw." + k, (1, 3, 9, 32, 32), torch.float32).to(torch.bfloat16).to(dev)
                      for k in cfgm.FORWARD_CONDITION_KEYS if k != "metallic"}          # one key missing -> zero latent + zero mask
             batch["video"] = batch["depth"]
             lat = model.prepare_diffusion_renderer_latent_conditions(batch)
             x0 = model.generate_samples_from_batch(dict(batch), guidance=0.0, seed=7, state_shape=[16, 2, 4, 4], num_steps=2,
                                                    init_noise=sw.synth_tensor("cw.n", (1, 16, 2, 4, 4), torch.float32, scale=80.0))
-            outs.append((lat, x0))
+            outs.append((lat, x0, model.decode(x0)))
         torch.cuda.synchronize()
-        q.put((rank, bool(torch.equal(outs[0][0], outs[1][0])), bool(torch.equal(outs[0][1], outs[1][1])),
-               tuple(outs[0][0].shape)))
+        q.put((rank, bool(torch.equal(outs[0][0], outs[1][0])),
+               bool(torch.equal(outs[0][1], outs[1][1])) and bool(torch.equal(outs[0][2], outs[1][2])), tuple(outs[0][0].shape)))
     finally:
         dist.destroy_process_group()
 
 
 def test_condition_encodes_spread_over_ranks(gpu):
-    """Forward renderer on 2 ranks: each rank encodes every second condition map and the latents are all-gathered; the
-    condition latent and the sampled latent must equal the single-rank ones bit for bit."""
+    """Forward renderer on 2 ranks: each rank encodes every second condition map (alone, although its tokenizer could cut a map
+    into row bands) and the latents are all-gathered; the decode runs band-sharded.  Condition latent, sampled latent and
+    decoded video must equal the single-rank ones bit for bit."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
