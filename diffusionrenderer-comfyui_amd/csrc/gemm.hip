@@ -159,12 +159,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 // gemm256.hip: 256x256x64 ping-pong kernel for the large shapes
 int drn_gemm256_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                          int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                         void* stream);
+                         void* stream, const int64_t* blk);
 
 // gemm144.hip: 144x256x64 kernel (token bands of sequence parallelism: M = 2304 k)
 int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                          int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                         void* stream);
+                         void* stream, const int64_t* blk);
 
 // Tile choice by a wave-quantisation model (measured on MI355X).  Time unit = one 256^2 workgroup owning a CU for the whole
 // K loop.  128^2 workgroups run two per CU at ~1000 vs ~1300 TF/s: a full round of 512 takes ~0.65 units.  A 144x256
@@ -202,12 +202,16 @@ static int pick_gemm_tile(int64_t M, int64_t N, double* cost_out = nullptr) {
 
 extern "C" int drn_gemm_tile_choice(int64_t M, int64_t N) { return pick_gemm_tile(M, N); }
 
-extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                             int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
-                             int64_t ldr, int64_t rows_per_batch, void* stream) {
+// blk = {a_shift, a_block_stride, c_shift, c_block_stride}; shift 62 = plain layout
+static const int64_t kPlain[4] = {62, 0, 62, 0};
+
+static int gemm_impl(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                     int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
+                     int64_t ldr, int64_t rows_per_batch, void* stream, const int64_t* blk) {
     DRN_CHECK_ARG(A && W && C && M >= 0 && N > 0 && K > 0);
     DRN_CHECK_ARG(K % BK == 0 && N % BN == 0);
-    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N);
+    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ldw >= K);
+    DRN_CHECK_ARG((blk[0] != 62 || lda >= K) && (blk[2] != 62 || ldc >= N));
     DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0);
     if (epilogue == DRN_EPI_GATE_RES)
         DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
@@ -215,6 +219,8 @@ extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, i
     if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
     double cost_all = 0.0;
     const int tile = pick_gemm_tile(M, N, &cost_all);
+    const bool blocked = blk[0] != 62 || blk[2] != 62;
+    if (blocked && tile == 0) return DRN_EINVAL;           // the 128x128 kernel has no blocked layouts (callers regroup instead)
     // A fractional last round of 256^2 workgroups idles CUs (72 x 16 tiles = 4.5 rounds cost 5).  Rows are independent, so the
     // tile rows that fill whole rounds run as one launch and the remaining rows as a second one with the tile that suits
     // them (DRN_GEMM_TAIL=0 switches this off).
@@ -231,24 +237,25 @@ extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, i
         const bool gate_ok = epilogue != DRN_EPI_GATE_RES || rows_per_batch >= M || M_main % rows_per_batch == 0;
         if (rounds >= 1 && rem != 0 && tm_main >= 1 && tm_main < tm && gate_ok) {
             double cost_tail = 0.0;
-            pick_gemm_tile(M - M_main, N, &cost_tail);
+            const int tail_tile = pick_gemm_tile(M - M_main, N, &cost_tail);
+            if (blocked && tail_tile == 0) cost_tail = 1e30;
             const double cost_split = (double)((tm_main * tn + 255) / 256) + cost_tail + 0.02;
             if (cost_split < cost_all - 0.05) {
                 const int rc = drn_gemm256_dispatch(A, W, C, M_main, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr,
-                                                    rows_per_batch, stream);
+                                                    rows_per_batch, stream, blk);
                 if (rc != DRN_OK) return rc;
                 const bf16_t* gate_t = (const bf16_t*)gate;
                 if (epilogue == DRN_EPI_GATE_RES && rows_per_batch < M) gate_t += (M_main / rows_per_batch) * N;
-                return drn_gemm_bf16((const bf16_t*)A + M_main * lda, W, (bf16_t*)C + M_main * ldc, M - M_main, N, K, lda, ldw, ldc,
-                                     epilogue, gate_t, residual ? (const bf16_t*)residual + M_main * ldr : nullptr, ldr,
-                                     rows_per_batch, stream);
+                return gemm_impl((const bf16_t*)A + M_main * lda, W, (bf16_t*)C + M_main * ldc, M - M_main, N, K, lda, ldw, ldc,
+                                 epilogue, gate_t, residual ? (const bf16_t*)residual + M_main * ldr : nullptr, ldr,
+                                 rows_per_batch, stream, blk);
             }
         }
     }
     if (tile == 1)
-        return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
+        return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
     if (tile == 2)
-        return drn_gemm144_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
+        return drn_gemm144_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
     DRN_CHECK_ARG(tiles < (1ll << 31));
     dim3 grid((unsigned)tiles), block(256);
@@ -263,4 +270,41 @@ extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, i
     }
 #undef ARGS
     return drn_launch_status();
+}
+
+extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                             int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
+                             int64_t ldr, int64_t rows_per_batch, void* stream) {
+    return gemm_impl(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, kPlain);
+}
+
+static int log2_exact(int64_t v) {
+    int s = 0;
+    while ((1ll << s) < v) ++s;
+    return (1ll << s) == v ? s : -1;
+}
+
+// Same product with operands stored in column blocks ("planes"): logical A[m][k] lives at
+// A + (k / a_block_cols) * a_block_stride + m * lda + k % a_block_cols, logical C[m][n] at
+// C + (n / c_block_cols) * c_block_stride + m * ldc + n % c_block_cols (block_cols = 0: plain).  Block widths are powers of
+// two, >= 64 for A and >= 256 for C.  Lets the sequence-parallel projections write the rank-major send buffer of the
+// head <-> token all-to-all directly, and the output projection read the rank-major receive buffer.
+extern "C" int drn_gemm_bf16_blocked(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                     int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
+                                     int64_t ldr, int64_t rows_per_batch, int64_t a_block_cols, int64_t a_block_stride,
+                                     int64_t c_block_cols, int64_t c_block_stride, void* stream) {
+    int64_t blk[4] = {62, 0, 62, 0};
+    if (a_block_cols) {
+        const int sh = log2_exact(a_block_cols);
+        DRN_CHECK_ARG(sh >= 6 && K % a_block_cols == 0 && a_block_stride % 8 == 0 && lda >= a_block_cols);
+        blk[0] = sh;
+        blk[1] = a_block_stride;
+    }
+    if (c_block_cols) {
+        const int sh = log2_exact(c_block_cols);
+        DRN_CHECK_ARG(sh >= 8 && N % c_block_cols == 0 && c_block_stride % 8 == 0 && ldc >= c_block_cols);
+        blk[2] = sh;
+        blk[3] = c_block_stride;
+    }
+    return gemm_impl(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
 }

@@ -29,7 +29,8 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
-                                                         const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP) {
+                                                         const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
+                                                         int abc, int64_t abs_, int cbc, int64_t cbs) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];     // NSTAGE * STAGE_BYTES, the ONLY LDS object
 
     const int tid = threadIdx.x;
@@ -81,7 +82,12 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
         }
     }
 #define DMA_W(P, SOFF, KT) __builtin_amdgcn_global_load_lds((gptr_t)(gw[P] + (int64_t)(KT) * BK), (lptr_t)(smem + (SOFF) + dw[P]), 16, 0, 0)
-#define DMA_A(P, SOFF, KT) __builtin_amdgcn_global_load_lds((gptr_t)(ga[P] + (int64_t)(KT) * BK), (lptr_t)(smem + (SOFF) + da[P]), 16, 0, 0)
+    // blocked operand layouts (drn_gemm_bf16_blocked): K step kt of A starts at element a_koff(kt) of a row; the tile's
+    // columns of C sit c_tile_off elements away from their plain position
+    // (block widths are powers of two, passed as shifts; shift 62 = plain layout: the formulas then reduce to k / 0 without a branch)
+#define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
+    const int64_t c_tile_off = (n0 >> cbc) * cbs + (n0 & ((1ll << cbc) - 1)) - n0;
+#define DMA_A(P, SOFF, KT) __builtin_amdgcn_global_load_lds((gptr_t)(ga[P] + A_KOFF(KT)), (lptr_t)(smem + (SOFF) + da[P]), 16, 0, 0)
 #define DMA_ALL(SOFF, KT)                                                           \
     do {                                                                            \
         DMA_W(0, SOFF, KT); DMA_W(1, SOFF, KT); DMA_W(2, SOFF, KT); DMA_W(3, SOFF, KT); \
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
                 uint2 o;                                                                                \
                 o.x = pack_bf2(v[0], v[1]);                                                             \
                 o.y = pack_bf2(v[2], v[3]);                                                             \
-                *reinterpret_cast<uint2*>(C + m * ldc + n) = o;                                         \
+                *reinterpret_cast<uint2*>(C + m * ldc + n + c_tile_off) = o;                            \
             }                                                                                           \
         }                                                                                               \
     } while (0)
@@ -242,7 +248,8 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
 
 template <int EPI>
 static int launch144(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                     int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st) {
+                     int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
+                     const int64_t* blk) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm144_kernel<EPI>),
@@ -260,19 +267,19 @@ static int launch144(const void* A, const void* W, void* C, int64_t M, int64_t N
     }
     gemm144_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), NSTAGE * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
-        ldr, rpb, group);
+        ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
     return drn_launch_status();
 }
 
 // called from drn_gemm_bf16 (gemm.hip) when 144-row tiles fill the CUs better than 256- or 128-row tiles
 int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                          int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                         void* stream) {
+                         void* stream, const int64_t* blk) {
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case DRN_EPI_NONE: return launch144<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st);
-        case DRN_EPI_GELU: return launch144<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st);
-        case DRN_EPI_GATE_RES: return launch144<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st);
+        case DRN_EPI_NONE: return launch144<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_GELU: return launch144<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_GATE_RES: return launch144<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
         default: return DRN_EINVAL;
     }
 }

@@ -39,7 +39,8 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
-                                                         const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP) {
+                                                         const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
+                                                         int abc, int64_t abs_, int cbc, int64_t cbs) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * STAGE_BYTES, the ONLY LDS object
 
     const int tid = threadIdx.x;
@@ -86,11 +87,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
             }
         }
     const int dma_off = wave * 2048;                                   // this wave's 2 KiB inside a half-tile region
+    // blocked operand layouts (drn_gemm_bf16_blocked): K step kt of A starts at element A_KOFF(kt) of a row; the tile's
+    // columns of C sit c_tile_off elements away from their plain position
+    // (block widths are powers of two, passed as shifts; shift 62 = plain layout: the formulas then reduce to k / 0 without a branch)
+#define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
+    const int64_t c_tile_off = (n0 >> cbc) * cbs + (n0 & ((1ll << cbc) - 1)) - n0;
 #define DMA(H, KT)                                                                                                     \
     do {                                                                                                               \
         char* dst_ = smem + ((KT) & 1) * STAGE_BYTES + (H) * HALF_BYTES + dma_off;                                     \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][0] + (int64_t)(KT) * BK), (lptr_t)dst_, 16, 0, 0);           \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][1] + (int64_t)(KT) * BK), (lptr_t)(dst_ + 1024), 16, 0, 0);  \
+        const int64_t ko_ = (H) < 2 ? A_KOFF(KT) : (int64_t)(KT) * BK;                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][0] + ko_), (lptr_t)dst_, 16, 0, 0);                          \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][1] + ko_), (lptr_t)(dst_ + 1024), 16, 0, 0);                 \
     } while (0)
 
     // ---- fragment read offsets inside a half-tile region (k-substep 1 = offset ^ 64)
@@ -230,14 +237,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
                     uint2 o;
                     o.x = pack_bf2(v[0], v[1]);
                     o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(C + m * ldc + n) = o;
+                    *reinterpret_cast<uint2*>(C + m * ldc + n + c_tile_off) = o;
                 }
         }
 }
 
 template <int EPI>
 static int launch256(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                     int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st) {
+                     int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
+                     const int64_t* blk) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
@@ -255,19 +263,19 @@ static int launch256(const void* A, const void* W, void* C, int64_t M, int64_t N
     }
     gemm256_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
-        ldr, rpb, group);
+        ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
     return drn_launch_status();
 }
 
 // called from drn_gemm_bf16 (gemm.hip) for large problems; arguments already validated there
 int drn_gemm256_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                          int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                         void* stream) {
+                         void* stream, const int64_t* blk) {
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case DRN_EPI_NONE: return launch256<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st);
-        case DRN_EPI_GELU: return launch256<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st);
-        case DRN_EPI_GATE_RES: return launch256<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st);
+        case DRN_EPI_NONE: return launch256<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_GELU: return launch256<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_GATE_RES: return launch256<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
         default: return DRN_EINVAL;
     }
 }

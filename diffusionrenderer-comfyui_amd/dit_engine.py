@@ -374,6 +374,7 @@ class HipDiT:
         pending = None
         site = 0
         nk = len(self.kinds)
+        fused = None                                             # a2a exchange: blocked-layout GEMMs instead of regroup passes
         for subs in self.blocks:
             for sb in subs:
                 m = mod[site]
@@ -402,11 +403,20 @@ class HipDiT:
                         # K|V go first so their exchange (RCCL's stream, 2/3 of the bytes) overlaps the Q projection.
                         W, hpr = D // world, self.heads // world
                         Oh, oback, rq, rkv = ws["oh"], ws["oback"], ws["rq"], ws["rkv"]
-                        N.gemm(Hb, sb["wqkv"][D:], out=ws["kvb"])
-                        N.permute_021(ws["kvb"].view(rows, world, 2 * W), out=ws["skv"])
+                        # (the projections write the rank-major send slabs themselves where the tile kernel can; else a regroup pass)
+                        if fused is None:
+                            fused = world > 1 and W >= 512 and N.gemm_blocked_ok(rows, 2 * D) and N.gemm_blocked_ok(rows, D)
+                        if fused:
+                            N.gemm_blocked(Hb, sb["wqkv"][D:], ws["skv"], rows, c_planes=True)
+                        else:
+                            N.gemm(Hb, sb["wqkv"][D:], out=ws["kvb"])
+                            N.permute_021(ws["kvb"].view(rows, world, 2 * W), out=ws["skv"])
                         work_kv = alltoall_rows_(ws["skv"], rkv.view(world, rows, 2 * W), self.pg, async_op=True)
-                        N.gemm(Hb, sb["wqkv"][:D], out=ws["qb"])
-                        N.permute_021(ws["qb"].view(rows, world, W), out=ws["sq"])
+                        if fused:
+                            N.gemm_blocked(Hb, sb["wqkv"][:D], ws["sq"], rows, c_planes=True)
+                        else:
+                            N.gemm(Hb, sb["wqkv"][:D], out=ws["qb"])
+                            N.permute_021(ws["qb"].view(rows, world, W), out=ws["sq"])
                         work_q = alltoall_rows_(ws["sq"], rq.view(world, rows, W), self.pg, async_op=True)
                         if work_kv is not None:
                             work_kv.wait()
@@ -419,6 +429,9 @@ class HipDiT:
                         work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
                         if work is not None:
                             work.wait()
+                        if fused:
+                            N.gemm_blocked(oback, sb["wo"], X, rows, epilogue=N.EPI_GATE_RES, gate=gate, residual=X, a_planes=True)
+                            continue
                         N.permute_021(oback, out=O.view(rows, world, W))
                     else:
                         # local projections; K|V land directly in this rank's band of the gather buffer.  K|V first, so the

@@ -22,6 +22,7 @@ SIGNATURES = {
     "drn_abi_version": [],
     "drn_error_string": [_I],
     "drn_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _P],
+    "drn_gemm_bf16_blocked": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _L, _L, _L, _L, _P],
     "drn_gemm_tile_choice": [_L, _L],
     "drn_gemm_force_tile": [_I],
     "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
@@ -164,6 +165,44 @@ def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_b
     _check(load_library().drn_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
                                         epilogue, _ptr(gate), _ptr(residual), ldr,
                                         rows_per_batch if rows_per_batch else max(M, 1), _stream()), "drn_gemm_bf16")
+    if t0 is not None:
+        _TIMER.end("gemm", t0, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1)))
+    return out
+
+
+def gemm_blocked_ok(M, N) -> bool:
+    """True when gemm_blocked can run an [M, N] output (every tile kernel but the 128x128 one has the blocked layouts)."""
+    return load_library().drn_gemm_tile_choice(M, N) != 0
+
+
+def gemm_blocked(a, w, out, M, epilogue=EPI_NONE, gate=None, residual=None, a_planes=False, c_planes=False):
+    """epi(A @ w^T) with A and / or C stored as planes of columns (drn_gemm_bf16_blocked).
+    a_planes: `a` is [P, M, Kb] contiguous = logical A[M, P*Kb] (plane p holds columns p*Kb ..);
+    c_planes: `out` is [P, M, Nb] contiguous = logical C[M, P*Nb].  Otherwise plain [M, K] / [M, N] row-strided views."""
+    _bf16(a, w, out, gate, residual)
+    N, K = w.shape
+    assert w.stride(1) == 1
+    if a_planes:
+        P, Ma, Kb = a.shape
+        assert a.is_contiguous() and Ma == M and P * Kb == K
+        lda, abc, abs_ = Kb, Kb, M * Kb
+    else:
+        assert a.shape == (M, K) and a.stride(1) == 1
+        lda, abc, abs_ = a.stride(0), 0, 0
+    if c_planes:
+        P, Mc, Nb = out.shape
+        assert out.is_contiguous() and Mc == M and P * Nb == N
+        ldc, cbc, cbs = Nb, Nb, M * Nb
+    else:
+        assert out.shape == (M, N) and out.stride(1) == 1
+        ldc, cbc, cbs = out.stride(0), 0, 0
+    ldr = residual.stride(0) if residual is not None else 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+    t0 = _TIMER.begin("gemm") if _TIMER is not None else None
+    _check(load_library().drn_gemm_bf16_blocked(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), ldc, epilogue,
+                                                _ptr(gate), _ptr(residual), ldr, max(M, 1), abc, abs_, cbc, cbs, _stream()),
+           "drn_gemm_bf16_blocked")
     if t0 is not None:
         _TIMER.end("gemm", t0, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1)))
     return out

@@ -52,6 +52,18 @@ int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, i
                   const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
                   void* stream);
 
+/* ---- the same product with operands stored in column blocks: logical A[m][k] at
+ * A + (k / a_block_cols) * a_block_stride + m * lda + k % a_block_cols, logical C[m][n] at
+ * C + (n / c_block_cols) * c_block_stride + m * ldc + n % c_block_cols (block_cols 0 = plain; powers of two, >= 64 for A,
+ * >= 256 for C).  New on this path (the reference has no multi-GPU code): the sequence-parallel K|V / Q projections write
+ * the rank-major send buffer of the head <-> token all-to-all directly and the output projection reads the rank-major
+ * receive buffer, instead of a regroup pass either side.  DRN_EINVAL when the shape would take the 128x128 kernel. */
+int drn_gemm_bf16_blocked(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
+                          int64_t lda, int64_t ldw, int64_t ldc, int epilogue,
+                          const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
+                          int64_t a_block_cols, int64_t a_block_stride, int64_t c_block_cols, int64_t c_block_stride,
+                          void* stream);
+
 /* ---- tuning hooks of drn_gemm_bf16 (no reference counterpart): which tile kernel the wave-quantisation model picks for an
  * [M, N] output (0: 128x128, 1: 256x256, 2: 144x256; N % 256 != 0 always takes 128x128), and a process-wide override for
  * A/B runs and tests (-1 = automatic). */

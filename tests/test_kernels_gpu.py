@@ -325,6 +325,33 @@ def test_gemm144_kernel(pkg, gpu, M, N, K, epi):
     test_gemm256_kernel(pkg, gpu, M, N, K, epi, tile=2)
 
 
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_blocked_layouts(pkg, gpu, tile):
+    """drn_gemm_bf16_blocked: C written as planes of columns / A read from planes of columns == the plain product regrouped
+    (the rank-major slabs either side of the sequence-parallel all-to-all)."""
+    lib = pkg.native.load_library()
+    M, N, K, P = 1152, 2048, 1024, 4
+    a, w = rnd((M, K), gpu, seed=90), rnd((N, K), gpu, K ** -0.5, seed=91)
+    lib.drn_gemm_force_tile(tile)
+    try:
+        plain = pkg.native.gemm(a, w)
+        cp = torch.zeros((P, M, N // P), dtype=BF, device=gpu)
+        pkg.native.gemm_blocked(a, w, cp, M, c_planes=True)
+        assert torch.equal(cp, plain.view(M, P, N // P).permute(1, 0, 2).contiguous())
+        ap = a.view(M, P, K // P).permute(1, 0, 2).contiguous()              # [P, M, K/P]
+        x, gate = rnd((M, N), gpu, seed=92), rnd((1, N), gpu, 0.5, seed=93)
+        ref = x.clone()
+        pkg.native.gemm(a, w, out=ref, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=ref)
+        out = x.clone()
+        pkg.native.gemm_blocked(ap, w, out, M, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out, a_planes=True)
+        assert torch.equal(out, ref)
+        assert pkg.native.gemm_blocked_ok(M, N)
+    finally:
+        lib.drn_gemm_force_tile(-1)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        pkg.native.gemm_blocked(a[:64], w, torch.zeros((P, 64, N // P), dtype=BF, device=gpu), 64, c_planes=True)   # 128x128 kernel
+
+
 def test_gemm144_identity_and_choice(pkg, gpu):
     lib = pkg.native.load_library()
     M = K = 2304 // 2

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, exchange):
+def _worker(rank, world, port, q, exchange, wide=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["DRN_SP_EXCHANGE"] = exchange
@@ -35,11 +35,16 @@ def _worker(rank, world, port, q, exchange):
         from __graft_entry__ import load_package
         pkg = load_package()
         dev = torch.device("cuda:0")
-        net = tiny_net(pkg, 256, 2, 2)
+        net = tiny_net(pkg, 1024, 1, 8) if wide else tiny_net(pkg, 256, 2, 2)
+        lat = (2, 64, 64) if wide else (2, 16, 16)
         sw = pkg.synthetic_weights
         sd = sw.synth_state_dict(net, torch.bfloat16, device=dev)
-        x = sw.synth_tensor("pg.x", (1, 16, 2, 16, 16), torch.float32, scale=2.0).to(torch.bfloat16).to(dev)
-        cond = sw.synth_tensor("pg.c", (1, 16, 2, 16, 16), torch.float32, scale=1.0).to(torch.bfloat16).to(dev)
+        x = sw.synth_tensor("pg.x", (1, 16) + lat, torch.float32, scale=2.0).to(torch.bfloat16).to(dev)
+        cond = sw.synth_tensor("pg.c", (1, 16) + lat, torch.float32, scale=1.0).to(torch.bfloat16).to(dev)
+        if wide:
+            # heads/world * 128 = 512 columns per rank: the projections write / read the rank-major slabs through the
+            # blocked-layout GEMM (forced onto the 256^2 tile: the cost model keeps shapes this small on the 128^2 kernel)
+            pkg.native.load_library().drn_gemm_force_tile(1)
         single = pkg.dit_engine.HipDiT(net, sd, device=dev)
         sharded = pkg.dit_engine.HipDiT(net, sd, device=dev, process_group=dist.group.WORLD)
         assert sharded.exchange == exchange
@@ -51,13 +56,13 @@ def _worker(rank, world, port, q, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "gather"])
-def test_sharded_hipdit_equals_single_rank(gpu, exchange):
+@pytest.mark.parametrize("exchange,wide", [("a2a", False), ("gather", False), ("a2a", True)])
+def test_sharded_hipdit_equals_single_rank(gpu, exchange, wide):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, wide)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
