@@ -129,3 +129,21 @@ def test_forward_node_end_to_end(pkg, gpu):
     p2.device = gpu
     with pytest.raises(ValueError, match="channel count"):
         node.run_forward_pass(p2, g["depth"], g["normal"], g["roughness"], g["metallic"], g["base_color"], env, env_format="ball")
+
+
+def test_pipeline_error_behaviour(pkg, gpu):
+    """Errors at the boundary: no usable key, a clip batch > 1 (the reference cannot run it either), a pass-flag count
+    that does not match the context indices."""
+    net = tiny_net(pkg, 256, 1, 2)
+    p, _ = _pipeline(pkg, gpu, net, StubVAE(), 0.0, 1)
+    with pytest.raises(ValueError, match="No suitable input tensor"):
+        p.generate_video({"context_index": torch.zeros((1, 1), dtype=torch.long)})
+    rgb2 = pkg.synthetic_weights.synth_tensor("err.rgb", (2, 3, 1, 64, 64), torch.float32)
+    with pytest.raises(ValueError, match="one clip per call"):
+        p.generate_video({"rgb": rgb2, "video": rgb2, "context_index": torch.zeros((2, 1), dtype=torch.long)})
+    rgb = rgb2[:1]
+    idx = torch.tensor([[0], [3]], dtype=torch.long)
+    with pytest.raises(ValueError, match="normalize_normal flags"):
+        p.generate_video_passes({"rgb": rgb, "video": rgb, "context_index": idx}, normalize_normal=[False])
+    outs = p.generate_video_passes({"rgb": rgb, "video": rgb, "context_index": idx}, normalize_normal=[False, True], seed=1)
+    assert len(outs) == 2 and outs[0].shape == (1, 1, 64, 64, 3) and outs[0].dtype.name == "uint8"
