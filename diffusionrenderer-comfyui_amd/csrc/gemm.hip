@@ -31,7 +31,8 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                            bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                                            int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
-                                                           const bf16_t* R, int64_t ldr, int64_t rpb) {
+                                                           const bf16_t* R, int64_t ldr, int64_t rpb,
+                                                           float* __restrict__ part) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x;
@@ -102,12 +103,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)(K / BK);
-    stage(0, 0);
+    // split-K (gridDim.y > 1, small M: too few tiles to keep the CUs streaming weights): this workgroup multiplies K steps
+    // [kbeg, kbeg + nk) and stores its fp32 partial tile; gemm_splitk_epilogue_kernel sums the partials and applies the epilogue
+    const int nk = (int)(K / BK) / (int)gridDim.y;
+    const int kbeg = (int)blockIdx.y * nk;
+    stage(kbeg, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk) stage(kbeg + kt + 1, (kt + 1) & 1);
         const char* sa = smem + (kt & 1) * STAGE_BYTES;
         const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -125,6 +129,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
     }
 
+    if (part) {                                                   // split-K partial: fp32, [split][M][N]
+        float* pp = part + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + wm * 64 + i * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4_t*>(pp + m * N + n0 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+        }
+        return;
+    }
     // ---- epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -153,6 +169,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
             o.y = pack_bf2(v[2], v[3]);
             *reinterpret_cast<uint2*>(C + m * ldc + n) = o;
         }
+    }
+}
+
+// sum of the split-K partials + the fused epilogue (same arithmetic as the in-kernel epilogue on the fp32 total)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const float* __restrict__ part, int splits, bf16_t* C,
+                                                                   int64_t M, int64_t N, int64_t ldc,
+                                                                   const bf16_t* __restrict__ gate, const bf16_t* R,
+                                                                   int64_t ldr, int64_t rpb) {
+    const int64_t nq = N / 4, total = M * nq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nq, n = (i - m * nq) * 4;
+        f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + m * N + n);
+        for (int s = 1; s < splits; ++s) a += *reinterpret_cast<const f32x4_t*>(part + ((int64_t)s * M + m) * N + n);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(a[r]);
+        if (EPI == DRN_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+        } else if (EPI == DRN_EPI_GATE_RES) {
+            const uint2 g2 = *reinterpret_cast<const uint2*>(gate + (m / rpb) * N + n);
+            const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);
+            const float g[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
+            const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(C + m * ldc + n) = o;
     }
 }
 
@@ -261,7 +309,7 @@ static int gemm_impl(const void* A, const void* W, void* C, int64_t M, int64_t N
     dim3 grid((unsigned)tiles), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define ARGS (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, \
-             (const bf16_t*)residual, ldr, rows_per_batch
+             (const bf16_t*)residual, ldr, rows_per_batch, (float*)nullptr
     switch (epilogue) {
         case DRN_EPI_NONE: gemm_bf16_kernel<DRN_EPI_NONE><<<grid, block, 0, st>>>(ARGS); break;
         case DRN_EPI_GELU: gemm_bf16_kernel<DRN_EPI_GELU><<<grid, block, 0, st>>>(ARGS); break;
@@ -307,4 +355,50 @@ extern "C" int drn_gemm_bf16_blocked(const void* A, const void* W, void* C, int6
         blk[3] = c_block_stride;
     }
     return gemm_impl(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
+}
+
+// ---- split-K for small M (weight-streaming regime): `splits` workgroups per output tile, fp32 partials in `workspace`
+extern "C" int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits) {
+    return splits > 1 ? (int64_t)splits * M * N * (int64_t)sizeof(float) : 0;
+}
+
+// how many K splits keep the CUs busy for an [M, N, K] product (1 = none): at most half of the 512 workgroup slots filled by
+// 128^2 tiles, at most 512 workgroups after the split and at least 16 K steps left per split
+extern "C" int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
+    if (N % BN != 0 || K % BK != 0 || M <= 0) return 1;
+    if (pick_gemm_tile(M, N) != 0) return 1;
+    const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
+    int best = 1;
+    for (int s = 2; s <= 8; s *= 2)
+        if (tiles * s <= 512 && (K / BK) % s == 0 && K / s >= 1024) best = s;
+    return tiles <= 256 ? best : 1;
+}
+
+extern "C" int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                    int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
+                                    int64_t ldr, int64_t rows_per_batch, int splits, void* workspace, void* stream) {
+    if (splits <= 1)
+        return drn_gemm_bf16(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream);
+    DRN_CHECK_ARG(A && W && C && workspace && M > 0 && N > 0 && K > 0 && splits <= 64);
+    DRN_CHECK_ARG(K % BK == 0 && N % BN == 0 && (K / BK) % splits == 0);
+    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N);
+    DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)workspace & 15) == 0);
+    if (epilogue == DRN_EPI_GATE_RES)
+        DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
+    if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
+    const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
+    DRN_CHECK_ARG(tiles < 65536);
+    hipStream_t st = (hipStream_t)stream;
+    gemm_bf16_kernel<DRN_EPI_NONE><<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st>>>(
+        (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, nullptr, nullptr, 0, 1, (float*)workspace);
+    int64_t blocks = (M * (N / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+#define EARGS (const float*)workspace, splits, (bf16_t*)C, M, N, ldc, (const bf16_t*)gate, (const bf16_t*)residual, ldr, rows_per_batch
+    switch (epilogue) {
+        case DRN_EPI_NONE: gemm_splitk_epilogue_kernel<DRN_EPI_NONE><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(EARGS); break;
+        case DRN_EPI_GELU: gemm_splitk_epilogue_kernel<DRN_EPI_GELU><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(EARGS); break;
+        default: gemm_splitk_epilogue_kernel<DRN_EPI_GATE_RES><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(EARGS); break;
+    }
+#undef EARGS
+    return drn_launch_status();
 }

@@ -23,6 +23,9 @@ SIGNATURES = {
     "drn_error_string": [_I],
     "drn_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _P],
     "drn_gemm_bf16_blocked": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _L, _L, _L, _L, _P],
+    "drn_gemm_bf16_splitk": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _I, _P, _P],
+    "drn_gemm_splitk_workspace_bytes": [_L, _L, _I],
+    "drn_gemm_splitk_choice": [_L, _L, _L],
     "drn_gemm_tile_choice": [_L, _L],
     "drn_gemm_force_tile": [_I],
     "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
@@ -41,7 +44,8 @@ SIGNATURES = {
     "drn_cfg_combine": [_P, _P, _P, _L, _F, _P],
     "drn_postprocess_u8": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64}
+_RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64,
+             "drn_gemm_splitk_workspace_bytes": c_int64}
 
 
 def library_path() -> str:
@@ -149,7 +153,7 @@ def set_timer(t):
 
 # ----------------------------------------------------------------------------------------------- wrappers
 
-def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_batch=None):
+def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_batch=None, splitk=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T).  a/w/out may be row-strided 2-D views (last dim contiguous)."""
     _bf16(a, w, out, gate, residual)
     M, K = a.shape
@@ -162,9 +166,23 @@ def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_b
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     t0 = _TIMER.begin("gemm") if _TIMER is not None else None
-    _check(load_library().drn_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
-                                        epilogue, _ptr(gate), _ptr(residual), ldr,
-                                        rows_per_batch if rows_per_batch else max(M, 1), _stream()), "drn_gemm_bf16")
+    lib = load_library()
+    rpb = rows_per_batch if rows_per_batch else max(M, 1)
+    splits = lib.drn_gemm_splitk_choice(M, N, K) if (M <= 1024 and splitk is None) else (splitk or 1)
+    if splits > 1:
+        # few tokens: the product streams the weights; K is split over several workgroups per tile to keep the CUs busy
+        nbytes = lib.drn_gemm_splitk_workspace_bytes(M, N, splits)
+        key = (a.device, "gemm")
+        ws = _SPLIT_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+            _SPLIT_WS[key] = ws
+        _check(lib.drn_gemm_bf16_splitk(_ptr(a), _ptr(w), _ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), epilogue,
+                                        _ptr(gate), _ptr(residual), ldr, rpb, splits, ws.data_ptr(), _stream()),
+               "drn_gemm_bf16_splitk")
+    else:
+        _check(lib.drn_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+                                 epilogue, _ptr(gate), _ptr(residual), ldr, rpb, _stream()), "drn_gemm_bf16")
     if t0 is not None:
         _TIMER.end("gemm", t0, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1)))
     return out

@@ -64,6 +64,17 @@ int drn_gemm_bf16_blocked(const void* A, const void* W, void* C, int64_t M, int6
                           int64_t a_block_cols, int64_t a_block_stride, int64_t c_block_cols, int64_t c_block_stride,
                           void* stream);
 
+/* ---- the same product for small M (a few hundred tokens: cfg 1, weight-streaming bound): `splits` workgroups share the K
+ * range of every output tile so that enough CUs stream the weight matrix; fp32 partials go to `workspace`
+ * (drn_gemm_splitk_workspace_bytes), a second kernel sums them and applies the epilogue.  drn_gemm_splitk_choice returns the
+ * split count the dispatcher would use for a shape (1 = plain drn_gemm_bf16). */
+int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
+                         int64_t lda, int64_t ldw, int64_t ldc, int epilogue,
+                         const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
+                         int splits, void* workspace, void* stream);
+int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
+int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K);
+
 /* ---- tuning hooks of drn_gemm_bf16 (no reference counterpart): which tile kernel the wave-quantisation model picks for an
  * [M, N] output (0: 128x128, 1: 256x256, 2: 144x256; N % 256 != 0 always takes 128x128), and a process-wide override for
  * A/B runs and tests (-1 = automatic). */

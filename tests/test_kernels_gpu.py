@@ -352,6 +352,36 @@ def test_gemm_blocked_layouts(pkg, gpu, tile):
         pkg.native.gemm_blocked(a[:64], w, torch.zeros((P, 64, N // P), dtype=BF, device=gpu), 64, c_planes=True)   # 128x128 kernel
 
 
+@pytest.mark.parametrize("M,N,K,epi,splits", [(256, 4096, 4096, 0, 4), (256, 4096, 16384, 2, 8), (200, 512, 2048, 1, 2),
+                                              (512, 1024, 1024, 2, None), (77, 256, 4096, 1, 4)])
+def test_gemm_splitk_small_m(pkg, gpu, M, N, K, epi, splits):
+    """Few tokens (cfg 1): K split over several workgroups per tile, fp32 partials summed by the epilogue kernel."""
+    a, w = rnd((M, K), gpu, seed=95), rnd((N, K), gpu, K ** -0.5, seed=96)
+    lin = (a.float() @ w.float().t()).to(BF)
+    mag = None
+    kw = {"splitk": splits}
+    if epi == 0:
+        out, ref = pkg.native.gemm(a, w, **kw), lin
+    elif epi == 1:
+        out, ref = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GELU, **kw), F.gelu(lin.cpu()).to(gpu)
+    else:
+        x, gate = rnd((M, N), gpu, seed=97), rnd((1, N), gpu, 0.5, seed=98)
+        ref = x + gate * lin
+        mag = torch.maximum(x.abs(), (gate * lin).abs())
+        out = x.clone()
+        pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out, **kw)
+    ok, msg = ulp_diff_ok(out, ref, max_ulp=2, frac_exact=0.97, mag=mag)
+    assert ok, msg
+
+
+def test_gemm_splitk_choice(pkg):
+    f = pkg.native.load_library().drn_gemm_splitk_choice
+    assert f(256, 4096, 4096) == 4 and f(256, 4096, 16384) == 8      # out-proj / MLP-down at S = 256
+    assert f(256, 12288, 4096) == 2 and f(256, 16384, 4096) == 2     # QKV / MLP-up
+    assert f(18432, 4096, 4096) == 1 and f(2048, 4096, 4096) == 1    # enough tiles already
+    assert f(256, 256, 256) == 1                                     # K too short to split
+
+
 def test_gemm144_identity_and_choice(pkg, gpu):
     lib = pkg.native.load_library()
     M = K = 2304 // 2
