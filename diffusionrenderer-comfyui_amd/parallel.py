@@ -17,7 +17,7 @@ Two exchanges implement that one dependency:
 * K|V all-gather (fallback, any world that divides S): every rank receives all other bands' K and V rows
   (S * 2D * 2 B * 7/8 = 264 MB per layer and rank).
 """
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist

@@ -1,4 +1,4 @@
-import torch, time
+import torch
 dev = torch.device("cuda")
 S, D = 18432, 4096
 for (M, N, K) in [(S, 3*D, D), (S, D, D), (S, 4*D, D), (S, D, 4*D), (2304, 4*D, D), (2304, D, 4*D)]:
