@@ -1,3 +1,8 @@
+"""Library yardstick for DESIGN.md: torch.nn.functional.linear (hipBLASLt / rocBLAS, plain GEMM without epilogue) on the DiT's
+linear shapes at cfg 3, full clip and 8-way token band.  Not used by the product path.
+
+    python tools/libgemm_ref.py
+"""
 import torch
 dev = torch.device("cuda")
 S, D = 18432, 4096
