@@ -249,6 +249,15 @@ def main():
                     "per_kernel": {k: {"tflops": round(v["flops"] / (v["ms_total"] * 1e-3) / 1e12, 1),
                                        "ms_per_step": round(v["ms_avg"] * v.get("launches_seen", v["launches"]) / args.steps, 2)}
                                    for k, v in summ.items()}}
+        if timer is None:
+            # small clips (S <= 4096): a forward is a weight stream (HBM roofline); per-launch event pairs would cost
+            # ~9 % of a 7 ms step, so the rate is the executed linears' weight bytes over the WHOLE step (a lower bound on the
+            # GEMM kernels' own rate)
+            wbytes = 12.0 * 4096 * 4096 * 2 * args.blocks
+            gbs = wbytes / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "gemm_bf16_kernel (split-K)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                        "note": "weight bytes of the executed linears / whole step time (no per-launch events at this size)"}
         out = {
             "metric": "denoising_steps_per_sec", "value": round(steps_s, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
