@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=28, help="debug only; the headline number needs 28")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tokenizer", action="store_true", help="skip the (untimed) tokenizer encode/decode leg")
+    ap.add_argument("--no-cfg", action="store_true", help="skip the secondary guidance-2.0 (cond + uncond) figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +194,27 @@ def main():
         elapsed = tmax.item()
     assert torch.isfinite(xt.float()).all(), "non-finite latent"
 
+    # ---- secondary figure: the same step at the pipeline's default guidance 2.0 = cond + uncond forwards, which the
+    #      sampler runs as ONE batch of two clips; one warm-up + two timed steps, outside the headline's timed region
+    cfg_ms = None
+    if not args.no_cfg:
+        def cfg_step(i, x):
+            t = model.scheduler.timesteps[i]
+            xs = model.scheduler.scale_model_input(x, timestep=t)
+            both = model.net(x=torch.cat([xs, xs], 0), timesteps=t, latent_condition=torch.cat([cond, torch.zeros_like(cond)], 0),
+                             context_index=[3, 0])
+            out = N.cfg_combine(both[:1].contiguous(), both[1:].contiguous(), 2.0)
+            model.scheduler.current_step = i
+            return model.scheduler.step(out, t, x).prev_sample
+        xg = cfg_step(0, xt)
+        barrier()
+        t0 = time.perf_counter()
+        for i in (0, 1):
+            xg = cfg_step(i, xg)
+        barrier()
+        cfg_ms = (time.perf_counter() - t0) / 2 * 1e3
+        del xg
+
     # ---- tokenizer leg (rank 0, outside the timed region): one encode + one decode of the full clip, for frames/s and the
     #      conv kernel's achieved HBM rate.  Random-init CV8x8x8 weights; synthetic RGB clip resident in HBM.
     tok = None
@@ -273,6 +295,9 @@ def main():
             "frames_per_sec_35step_pass_dit_only": round(args.frames / (35 * ms * 1e-3), 3),
             "roofline": roofline,
         }
+        if cfg_ms is not None:
+            out["guidance_2"] = {"steps_per_sec": round(1e3 / cfg_ms, 4), "ms_per_step": round(cfg_ms, 2),
+                                 "note": "cond + uncond forwards of one Euler step as one batch of two clips (pipeline default guidance)"}
         if tok is not None:
             out["tokenizer"] = tok
             out["frames_per_sec_35step_pass"] = round(args.frames / ((tok["encode_ms"] + 35 * ms + tok["decode_ms"]) * 1e-3), 3)
