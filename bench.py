@@ -197,7 +197,7 @@ def main():
     # ---- secondary figure: the same step at the pipeline's default guidance 2.0 = cond + uncond forwards, which the
     #      sampler runs as ONE batch of two clips; one warm-up + two timed steps, outside the headline's timed region
     cfg_ms = None
-    if not args.no_cfg:
+    if not args.no_cfg and world == 1:          # (sharded runs: headline only, nothing extra that could cost the line)
         def cfg_step(i, x):
             t = model.scheduler.timesteps[i]
             xs = model.scheduler.scale_model_input(x, timestep=t)
