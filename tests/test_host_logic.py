@@ -22,3 +22,69 @@ def test_attention_plan_fills_whole_rounds(pkg):
         assert p[0][0] == 0 and p[-1][1] == args[2]
         for a, b in zip(p, p[1:]):
             assert a[1] == b[0] and a[1] % 256 == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# condition assembly against goldens captured from the reference's own _get_conditions /
+# prepare_diffusion_renderer_latent_conditions (model_diffusion_renderer.py:158-209; tools/make_goldens.py conditions_case)
+import json
+
+import pytest
+import torch
+
+from conftest import load_golden
+from stub_vae import StubVAE
+
+COND_KEYS8 = ["basecolor", "normal", "metallic", "roughness", "depth", "env_ldr", "env_log", "env_nrm"]
+
+
+def _cond_model(pkg, forward, mask, T, H, W, drop_keys=False):
+    cfgm = pkg.diffusion_renderer_config
+    cfg = (cfgm.get_forward_renderer_config if forward else cfgm.get_inverse_renderer_config)(H, W, T)
+    cfg = dict(cfg, append_condition_mask=mask)
+    if drop_keys:
+        cfg.pop("condition_keys")
+    m = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(cfg, device="cpu")   # host logic only: no weights, no GPU
+    m.vae = StubVAE()
+    return m
+
+
+@pytest.mark.parametrize("case,forward,mask,drop", [
+    ("forward.all8.mask", True, True, ()), ("forward.all8.nomask", True, False, ()),
+    ("forward.no_roughness.mask", True, True, ("roughness",)), ("forward.no_env.mask", True, True, ("env_ldr", "env_log", "env_nrm")),
+    ("inverse.rgb", False, None, ()), ("inverse.default_keys.mask", False, True, ())])
+def test_condition_assembly_equals_reference(pkg, case, forward, mask, drop):
+    gold, meta = load_golden("conditions.safetensors")
+    T, (H, W) = int(meta["T"]), json.loads(meta["HW"])
+    sw = pkg.synthetic_weights
+    assert pkg.diffusion_renderer_config.get_forward_renderer_config(H, W, T)["condition_keys"] == json.loads(meta["forward_keys"])
+    assert pkg.diffusion_renderer_config.get_inverse_renderer_config(H, W, T)["condition_keys"] == json.loads(meta["inverse_keys"])
+
+    def clip(k):
+        return sw.synth_tensor("cond8." + k, (1, 3, T, H, W), torch.float32, scale=1.0).to(torch.bfloat16)
+
+    if forward:
+        batch = {k: clip(k) for k in COND_KEYS8 if k not in drop}
+    else:
+        rgb = clip("rgb")
+        batch = {"rgb": rgb, "video": rgb}
+    if mask is None:
+        mask = meta["inverse_mask"] == "True"
+    m = _cond_model(pkg, forward, mask, T, H, W, drop_keys=(case == "inverse.default_keys.mask"))
+    cond, uncond = m._get_conditions(batch)
+    lc = cond.to_dict()["latent_condition"]
+    assert lc.dtype == gold[case].dtype and torch.equal(lc, gold[case]), case
+    assert batch["latent_condition"] is lc                          # the reference writes it into the batch too
+    assert not uncond.to_dict()["latent_condition"].any()           # uncond = zeros_like (CleanConditioner :88-96)
+    want_key = json.loads(meta["input_data_key"]).get(case.rsplit(".", 1)[0] if forward else case)
+    if want_key:
+        assert m.input_data_key == want_key
+
+
+def test_condition_assembly_errors_like_reference(pkg):
+    m = _cond_model(pkg, True, True, 9, 32, 48)
+    with pytest.raises(ValueError):                                  # no condition key present -> no latent shape (:177-178)
+        m.prepare_diffusion_renderer_latent_conditions({"video": torch.zeros(1, 3, 9, 32, 48)})
+    m.vae = None
+    with pytest.raises(RuntimeError):
+        m.prepare_diffusion_renderer_latent_conditions({"basecolor": torch.zeros(1, 3, 9, 32, 48)})

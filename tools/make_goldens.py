@@ -284,6 +284,147 @@ def manifest_case(ref):
     print("wrote", path, {k: len(v) for k, v in out.items()})
 
 
+COND_KEYS8 = ["basecolor", "normal", "metallic", "roughness", "depth", "env_ldr", "env_log", "env_nrm"]
+
+
+def conditions_case(ref):
+    """Condition assembly of both renderers through the REFERENCE's own `_get_conditions` /
+    `prepare_diffusion_renderer_latent_conditions` (model_diffusion_renderer.py:158-209) with the stub tokenizer:
+    forward 8 keys x (16 latent + mask), one key missing (zeros + zero mask), without the mask, and the inverse
+    renderer's `image` -> `rgb` alias.  Inputs come from synth_tensor('cond8.<key>', ...); only outputs are stored."""
+    out = {}
+    T, H, W = 9, 32, 48
+
+    def maps(keys):
+        return {k: sw.synth_tensor("cond8." + k, (1, 3, T, H, W), torch.float32, scale=1.0).to(torch.bfloat16) for k in keys}
+
+    def run(cfg, batch, mask):
+        cfg = dict(cfg, net=dict(cfg["net"], model_channels=128, num_blocks=1, num_heads=1), scheduler=dict(cfg["scheduler"]),
+                   append_condition_mask=mask)
+        m = ref.model.CleanDiffusionRendererModel(cfg)
+        m.vae = StubVAE()
+        batch = dict(batch)
+        cond, uncond = m._get_conditions(batch)
+        lc = cond.to_dict()["latent_condition"]
+        assert torch.equal(batch["latent_condition"], lc)
+        assert not uncond.to_dict()["latent_condition"].any()
+        return lc.contiguous(), m.input_data_key
+
+    fwd = ref.config.get_forward_renderer_config(H, W, T)
+    inv = ref.config.get_inverse_renderer_config(H, W, T)
+    assert fwd["condition_keys"] == COND_KEYS8
+    b8 = maps(COND_KEYS8)
+    out["forward.all8.mask"], k1 = run(fwd, b8, True)
+    out["forward.all8.nomask"], _ = run(fwd, b8, False)
+    b7 = {k: v for k, v in b8.items() if k != "roughness"}
+    out["forward.no_roughness.mask"], _ = run(fwd, b7, True)
+    b5 = {k: v for k, v in b8.items() if not k.startswith("env_")}
+    out["forward.no_env.mask"], k2 = run(fwd, b5, True)
+    rgb = maps(["rgb"])
+    inv_keys = inv["condition_keys"]
+    out["inverse.rgb"], k3 = run(inv, {"rgb": rgb["rgb"], "video": rgb["rgb"]}, inv.get("append_condition_mask", True))
+    # the model's own default key list (no `condition_keys` in the config): ["image", "rgb"] -> alias + the rgb key itself
+    inv_default = {k: v for k, v in inv.items() if k != "condition_keys"}
+    out["inverse.default_keys.mask"], _ = run(inv_default, {"rgb": rgb["rgb"], "video": rgb["rgb"]}, True)
+    meta = dict(META_COMMON, case="condition assembly", T=str(T), HW=json.dumps([H, W]), forward_keys=json.dumps(COND_KEYS8),
+                inverse_keys=json.dumps(inv_keys), inverse_mask=str(inv.get("append_condition_mask", True)),
+                input_data_key=json.dumps({"forward.all8": k1, "forward.no_env": k2, "inverse.rgb": k3}),
+                vae="StubVAE (tools/make_goldens.py)",
+                inputs="synth_tensor('cond8.'+key,(1,3,T,H,W),fp32,scale=1).to(bf16) per key")
+    return out, meta
+
+
+def full_width_cases(ref):
+    """The 7.2 B-parameter model (28 blocks, D = 4096, 32 heads) through the reference at BASELINE config 2's two token
+    counts (latent (1,64,64) -> S = 1024 and (2,64,64) -> S = 2048) and SURVEY 8c G4: the 4-step config-1 pipeline run
+    (1 frame 256 x 256, guidance 0) whose trajectory is re-traced by the oracle from the x_T the reference drew.
+    The reference model is built once; its parameters ARE the synthetic state dict (load_state_dict(assign=True))."""
+    cfg, net = net_config(ref, 4096, 28, 32)
+    sd = sw.synth_state_dict(net, torch.bfloat16)
+    cfgm = dict(cfg, net=dict(net), scheduler=dict(cfg["scheduler"]))
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        model = ref.model.CleanDiffusionRendererModel(cfgm)
+    finally:
+        torch.set_default_dtype(prev)
+    model = model.to(torch.bfloat16)
+    missing, unexpected = model.load_state_dict(sd, strict=False, assign=True)
+    assert not unexpected and all("dim_spatial_range" in m or "dim_temporal_range" in m for m in missing), (missing, unexpected)
+    model.eval()
+    gc.collect()
+    orc = O.DitOracle(sd, net, dtype=torch.bfloat16)
+    files = {}
+
+    fwd_cases = [("full28_s1024", (1, 64, 64), 1.5, 0), ("full28_s2048", (2, 64, 64), 12.0, 4)]
+    fwd_inputs = {}
+    for tag, latent, sigma, ci_ in fwd_cases:
+        t0 = time.time()
+        x, cond = inputs_for(tag, latent, 16, torch.bfloat16)
+        t, ci = torch.tensor(sigma, dtype=torch.float32), torch.full((1, 1), ci_, dtype=torch.long)
+        with torch.no_grad():
+            y = model.net(x=x, timesteps=t, latent_condition=cond, context_index=ci)
+            yo = orc.forward(x, t, cond, ci)
+        assert torch.equal(y, yo), f"{tag}: oracle != reference"
+        files[tag] = ({"out.bf16": y.contiguous()},
+                      dict(META_COMMON, case=tag, D="4096", L="28", heads="32", latent=json.dumps(latent), sigma=repr(sigma),
+                           context_index=str(ci_), forward="False",
+                           inputs="synth_tensor(tag+'.x',(1,16,F,h,w),fp32,scale=2).to(bf16); synth_tensor(tag+'.cond',...,scale=1).to(bf16)"))
+        fwd_inputs[tag] = (x, t, cond, ci)
+        print(f"{tag}: reference + oracle bf16 forwards {time.time()-t0:.0f}s", flush=True)
+
+    # G4: whole pipeline, 4 steps, guidance 0, normal pass (context 3, re-normalisation on), 1 frame 256 x 256
+    t0 = time.time()
+    tag, steps, seed = "g4", 4, 42
+    p = ref.pipeline.CleanDiffusionRendererPipeline("/nonexistent", "x.pt", model_type=None, vae_instance=StubVAE(),
+                                                    model_instance=model, guidance=0.0, num_steps=steps, seed=seed)
+    p.device = torch.device("cpu")
+    p.set_model_type("inverse")
+    rgb = sw.synth_tensor(tag + ".rgb", (1, 3, 1, 256, 256), torch.float32, scale=1.0)
+    ci = torch.full((1, 1), 3, dtype=torch.long)
+    video = p.generate_video({"rgb": rgb, "video": rgb, "context_index": ci}, normalize_normal=True, seed=seed)
+    vae = StubVAE()
+    torch.manual_seed(seed)
+    condl = (vae.encode(rgb.to(torch.bfloat16)) * 0.5).contiguous()
+    sig = O.edm_sigmas(steps)
+    xT = torch.randn(size=(1, 16, 1, 32, 32), dtype=torch.bfloat16) * sig[0]
+    traj = []
+    with torch.no_grad():
+        x0 = O.sample_loop(orc.forward, xT, condl, ci.to(torch.bfloat16), steps, 0.0, record=traj)
+        u8 = O.postprocess(vae.decode(x0 / 0.5), True).numpy()
+    assert (u8 == video).all(), "g4: oracle pipeline != reference pipeline"
+    g4 = {"xT": xT.contiguous(), "latent_condition": condl, "x0": x0.contiguous(), "video_u8": torch.from_numpy(video).contiguous()}
+    for i, s in enumerate(traj):
+        g4[f"traj.{i}"] = s.contiguous()
+    print(f"g4: reference pipeline + oracle trajectory {time.time()-t0:.0f}s", flush=True)
+
+    # exact answers: fp32 oracle with bf16-quantised host tables (parity bound, SURVEY 8d)
+    del model, p, orc
+    gc.collect()
+    orc32 = O.DitOracle(sd, net, dtype=torch.float32, tables_dtype=torch.bfloat16)
+    for tag, _, _, _ in fwd_cases:
+        t0 = time.time()
+        x, t, cond, ci2 = fwd_inputs[tag]
+        with torch.no_grad():
+            files[tag][0]["out.fp32_tables_bf16"] = orc32.forward(x, t, cond, ci2).contiguous()
+        print(f"{tag}: fp32 oracle {time.time()-t0:.0f}s", flush=True)
+    t0 = time.time()
+    traj32 = []
+    with torch.no_grad():
+        # the sampler's own roundings (bf16 latent between steps) kept; only the network evaluates in fp32
+        x0_32 = O.sample_loop(lambda xs, t, c, i: orc32.forward(xs, t, c, i).to(torch.bfloat16), xT, condl,
+                              ci.to(torch.bfloat16), steps, 0.0, record=traj32)
+    g4["x0.fp32net"] = x0_32.contiguous()
+    for i, s in enumerate(traj32):
+        g4[f"traj32.{i}"] = s.contiguous()
+    print(f"g4: fp32-network trajectory {time.time()-t0:.0f}s", flush=True)
+    files["g4"] = (g4, dict(META_COMMON, case="g4 full-width 4-step pipeline", D="4096", L="28", heads="32", T="1",
+                            HW=json.dumps([256, 256]), steps=str(steps), guidance="0.0", seed=str(seed), context_index="3",
+                            normalize_normal="True", vae="StubVAE (tools/make_goldens.py)",
+                            inputs="rgb = synth_tensor('g4.rgb',(1,3,1,256,256),fp32,scale=1)"))
+    return files
+
+
 def save(name, tensors, meta):
     os.makedirs(GOLD, exist_ok=True)
     path = os.path.join(GOLD, name)
@@ -324,6 +465,11 @@ def main():
         t, m = dit_case(ref, "wide1", 4096, 1, 32, (1, 32, 32), 2.0, 3, dtypes=(torch.bfloat16,))
         save("dit_wide1.safetensors", t, m)
         print(f"wide1 took {time.time()-t0:.1f}s")
+    if want("cond"):
+        save("conditions.safetensors", *conditions_case(ref))
+    if args.full and want("fullwidth"):
+        for tag, (t, m) in full_width_cases(ref).items():
+            save({"g4": "sampler_full28_cfg1_g4.safetensors"}.get(tag, f"dit_{tag}.safetensors"), t, m)
     if args.full and want("full"):
         t0 = time.time()
         t, m = dit_case(ref, "full28", 4096, 28, 32, (1, 32, 32), 2.0, 3, dtypes=(torch.bfloat16,), keep_blocks=False)
