@@ -1,9 +1,8 @@
 // Non-causal flash attention forward for head_dim 128 on gfx950 (replaces F.scaled_dot_product_attention +
 // the sbhd<->bhsd permutes + the head flatten, CleanGeneralDIT.py:181-203, :299-304).
 //
-// Workgroup = 8 waves = 256 query rows (32 per wave), KV tile = 64 keys, K and V tiles double-buffered in LDS
-// (register-staged: the next tile's global loads are issued before the current tile's MFMAs and written to LDS
-// after them, one barrier per tile).
+// Workgroup = 8 waves = 256 query rows (32 per wave), KV tile = 64 keys.  K tiles triple-, V tiles quadruple-buffered in LDS,
+// filled by global->LDS DMA (global_load_lds_dwordx4, swizzle on the source address) two tiles ahead.
 //
 // Per wave and KV tile (v_mfma_f32_32x32x16_bf16 only):
 //   S^T[key][q]  = K . Q^T          A = K rows (ds_read_b128, XOR-swizzled 256-B rows), B = Q (registers)
@@ -13,34 +12,53 @@
 //       lane movement; the k order inside a 16-step is permuted: element j of lane half h is key
 //       16s + 8(j>>2) + 4h + (j&3)), A = V^T read with ds_read_b64_tr_b16 in that same key order.
 //   O^T keeps the query on the lane too, so the online-softmax rescale is one per-lane scalar.
-//
 // Softmax in fp32 (exp2 with the scale folded in), P rounded to bf16 for the PV MFMA, row sum from the fp32 P.
+//
+// Schedule (measured on MI355X: with both waves of a SIMD free to run QK / softmax / PV as they come, the matrix work
+// (2.8 ms per launch at cfg 3) and everything else (softmax VALU, LDS / DMA issue: 2.8 ms) added up to 5.0 ms - the two
+// waves meet in their MFMA phases, contend for the one matrix pipe, then contend for the VALU).  So the tile loop is a
+// PING-PONG of two segments, the wave groups G0 = waves 0-3 and G1 = waves 4-7 (one wave of each per SIMD) half a tile apart:
+//     M(t) = PV(t-1) . QK(t)     32 MFMAs back to back; fragment reads issued between them, a block (8 MFMAs) ahead
+//     S(t) = softmax(t)          ~160 VALU + the tile prefetch DMA, no MFMA
+//     interval 2t:   G0 runs M(t),  G1 runs S(t-1)   | barrier |   interval 2t+1:  G0 runs S(t),  G1 runs M(t)   | barrier
+// so on every SIMD one wave feeds the matrix pipe while its partner's VALU work fills the issue slots between its MFMAs.
 #include "drn_common.h"
 
-// EXPV: ablation builds behind the stall budget quoted in DESIGN.md (1: no barrier, 2: no K/V staging, 4: no exp) -
-// timing only, results are wrong; the shipped library is built with 0.
-#ifndef EXPV
-#define EXPV 0
+// Build switches (A/B timing of variants in one process: tools/kbench.py --lib; the shipped library uses the defaults):
+//   ATT_EPI_LDS 1: O is transposed through LDS and stored as whole 256-B rows (16 B per lane); 0: 8-B row-strided stores.
+//   ATT_PRIO    1: a wave runs its MFMA segment at s_setprio 1 (its MFMAs win the issue arbitration against the partner's VALU).
+#ifndef ATT_EPI_LDS
+#define ATT_EPI_LDS 1
+#endif
+#ifndef ATT_PRIO
+#define ATT_PRIO 1
+#endif
+// ATT_ABL: timing-only ablation builds (results are WRONG; the shipped library is built with 0): 1 = no exp / row sum (softmax
+// VALU reduced to the max + bf16 pack), 2 = no barriers, 4 = no PV MFMAs, 8 = no QK MFMAs, 16 = no K/V DMA
+#ifndef ATT_ABL
+#define ATT_ABL 0
 #endif
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
+#define NKB 3            // K tile buffers
+#define NVB 4            // V tile buffers
 #ifndef RESCALE_THR
 #define RESCALE_THR 6.0f   // log2 units
 #endif
 
 typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ bf16x4_t ds_read_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)(p));
-}
+
 
 __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ Vp, bf16_t* __restrict__ O,
     int heads, int64_t Sq, int64_t Sk_total, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
     int64_t bsv, int64_t bso, float scale_log2e, int nqb, int total, int nsplit, int64_t kv_chunk,
     float* __restrict__ Opart, float* __restrict__ MLpart) {
-    __shared__ __attribute__((aligned(1024))) char smem[5 * KBYTES];   // K0 K1 V0 V1 V2
+    __shared__ __attribute__((aligned(1024))) char smem[(NKB + NVB) * KBYTES];   // K0..K2 V0..V3 - the ONLY LDS object
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,74 +97,88 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         const bf16_t* qp = Qb + qrow * ldq + 8 * lh;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
-        // make the Q loads complete HERE: otherwise hipcc keeps a decreasing vmcnt ladder in front of the QK^T MFMAs of
-        // every iteration (first-iteration hazard), which also drains the next tile's K/V loads far too early
+        // make the Q loads complete HERE: with a DMA in flight hipcc waits vmcnt(0) at the first use of any ordinary load
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
-    // ---- staging map: 1024 16-byte chunks per tile, two per thread per operand
-    int st_row[2], st_c[2], st_koff[2], st_voff[2];
+    // ---- staging: a K or V tile is 16 pieces of 1 KiB (4 rows x 256 B); wave w copies pieces 2w and 2w+1 of both by
+    //      global->LDS DMA.  The DMA writes LDS lane-linearly (lane i -> byte 16 i of the piece), so the swizzle sits on the
+    //      SOURCE address: the lane that fills chunk position cp of row r fetches chunk  cp ^ (r & 15)  (K, read back by
+    //      ds_read_b128) or  (((cp >> 2) ^ (r & 3)) << 2) | (cp & 3)  (V, read back by ds_read_b64_tr_b16); both are
+    //      involutions inside one 256-B row, so every row is still fetched as whole lines.
+    int st_row[2], st_kc[2], st_vc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int id = tid + 512 * i;
-        st_row[i] = id >> 4;
-        st_c[i] = id & 15;
-        st_koff[i] = st_row[i] * 256 + ((st_c[i] ^ (st_row[i] & 15)) << 4);
-        st_voff[i] = st_row[i] * 256 + ((((st_c[i] >> 2) ^ (st_row[i] & 3)) << 6) | ((st_c[i] & 3) << 4));
+        st_row[i] = 4 * (2 * wave + i) + (lane >> 4);
+        const int cp = lane & 15;
+        st_kc[i] = (cp ^ (st_row[i] & 15)) * 8;
+        st_vc[i] = ((((cp >> 2) ^ (st_row[i] & 3)) << 2) | (cp & 3)) * 8;
     }
-    // named registers (no arrays / lambdas: keeps the in-flight tile in VGPRs, not in a promoted alloca)
-    u32x4_t kreg0, kreg1, vreg0, vreg1;
-    const bf16_t* kp0 = Kb + (int64_t)st_row[0] * ldk + st_c[0] * 8;      // advanced by one tile per iteration
-    const bf16_t* kp1 = Kb + (int64_t)st_row[1] * ldk + st_c[1] * 8;
-    const bf16_t* vp0 = Vb + (int64_t)st_row[0] * ldv + st_c[0] * 8;
-    const bf16_t* vp1 = Vb + (int64_t)st_row[1] * ldv + st_c[1] * 8;
-    const int64_t kstep = (int64_t)KVT * ldk, vstep = (int64_t)KVT * ldv;
-#define LOAD_TILE(KV0)                                                                        \
+    const int dma_off = wave * 2048;
+    // per-lane BYTE offsets inside a tile (32-bit: 64 rows x ld); rows of the last, partial tile are clamped to its last key
+    // (their scores are masked in QK_MASK) - recomputed once, when that tile is about to be requested
+    uint32_t kso[2], vso[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        kso[i] = 2u * (uint32_t)(st_row[i] * (int)ldk + st_kc[i]);
+        vso[i] = 2u * (uint32_t)(st_row[i] * (int)ldv + st_vc[i]);
+    }
+    const int last_rows = (int)(Sk - (int64_t)((Sk - 1) / KVT) * KVT);        // keys in the last tile, 1..64
+#define CLAMP_LAST_TILE()                                                                     \
     do {                                                                                      \
-        if ((KV0) + KVT <= Sk) {                                                              \
-            kreg0 = *reinterpret_cast<const u32x4_t*>(kp0);                                   \
-            vreg0 = *reinterpret_cast<const u32x4_t*>(vp0);                                   \
-            kreg1 = *reinterpret_cast<const u32x4_t*>(kp1);                                   \
-            vreg1 = *reinterpret_cast<const u32x4_t*>(vp1);                                   \
-        } else { /* last, partial tile: clamp rows (masked below) */                          \
-            int64_t r0_ = (KV0) + st_row[0], r1_ = (KV0) + st_row[1];                         \
-            if (r0_ > Sk - 1) r0_ = Sk - 1;                                                   \
-            if (r1_ > Sk - 1) r1_ = Sk - 1;                                                   \
-            kreg0 = *reinterpret_cast<const u32x4_t*>(Kb + r0_ * ldk + st_c[0] * 8);          \
-            vreg0 = *reinterpret_cast<const u32x4_t*>(Vb + r0_ * ldv + st_c[0] * 8);          \
-            kreg1 = *reinterpret_cast<const u32x4_t*>(Kb + r1_ * ldk + st_c[1] * 8);          \
-            vreg1 = *reinterpret_cast<const u32x4_t*>(Vb + r1_ * ldv + st_c[1] * 8);          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
+            const int r_ = min(st_row[i], last_rows - 1);                                     \
+            kso[i] = 2u * (uint32_t)(r_ * (int)ldk + st_kc[i]);                               \
+            vso[i] = 2u * (uint32_t)(r_ * (int)ldv + st_vc[i]);                               \
         }                                                                                     \
-        kp0 += kstep; kp1 += kstep; vp0 += vstep; vp1 += vstep;                               \
     } while (0)
-#define WRITE_TILE(KBUF, VBUF)                                                                \
+#define DMA16(SRC, DST) __builtin_amdgcn_global_load_lds((gptr_t)(SRC), (lptr_t)(DST), 16, 0, 0)
+    // piece P (0..3: K0 V0 K1 V1) of tile TILE into K buffer KBUF / V buffer VBUF
+#define DMA_PIECE(P, TILE, KBUF, VBUF)                                                        \
     do {                                                                                      \
-        char* ks__ = smem + (KBUF) * KBYTES;                                                  \
-        char* vs__ = smem + (2 + (VBUF)) * KBYTES;                                            \
-        *reinterpret_cast<u32x4_t*>(ks__ + st_koff[0]) = kreg0;                               \
-        *reinterpret_cast<u32x4_t*>(vs__ + st_voff[0]) = vreg0;                               \
-        *reinterpret_cast<u32x4_t*>(ks__ + st_koff[1]) = kreg1;                               \
-        *reinterpret_cast<u32x4_t*>(vs__ + st_voff[1]) = vreg1;                               \
+        if ((P) & 1) {                                                                        \
+            const char* vt_ = reinterpret_cast<const char*>(Vb + (int64_t)(TILE) * KVT * ldv); \
+            DMA16(vt_ + vso[(P) >> 1], smem + (NKB + (VBUF)) * KBYTES + dma_off + ((P) >> 1) * 1024); \
+        } else {                                                                              \
+            const char* kt_ = reinterpret_cast<const char*>(Kb + (int64_t)(TILE) * KVT * ldk); \
+            DMA16(kt_ + kso[(P) >> 1], smem + (KBUF) * KBYTES + dma_off + ((P) >> 1) * 1024); \
+        }                                                                                     \
+    } while (0)
+#define STAGE_TILE(TILE, KBUF, VBUF)                                                          \
+    do {                                                                                      \
+        DMA_PIECE(0, TILE, KBUF, VBUF); DMA_PIECE(1, TILE, KBUF, VBUF);                       \
+        DMA_PIECE(2, TILE, KBUF, VBUF); DMA_PIECE(3, TILE, KBUF, VBUF);                       \
+    } while (0)
+    // this wave's DMA pieces have landed (the only vector-memory traffic inside the loop); the barrier that follows makes
+    // every wave's pieces visible.  Raw s_barrier: __syncthreads() would add lgkmcnt(0) and drain the fragment prefetch.
+#define DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory")
+#define BARRIER()                                                                             \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (!(ATT_ABL & 2)) __builtin_amdgcn_s_barrier();                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
     } while (0)
 
-    // ---- LDS read offsets
-    // K (A operand of S^T): row = 32*kt2 + lr, chunk = 2*ks + lh
-    int koff[2];
+    // ---- LDS read addresses, kept in a few MUTABLE registers that step from buffer to buffer (DS instructions take
+    //      VGPR + immediate only; left to hipcc, the dynamic buffer index turns into one hoisted address set per buffer)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((lptr_t)smem);
+    // K (A operand of S^T): row = 32*kt2 + lr, 16-B chunk (2*ks + lh) ^ (row & 15); kt2 = 1 is +8192 (immediate)
+    uint32_t ka[8];
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2) koff[kt2] = (32 * kt2 + lr) * 256;
-    const int kx = lr & 15;          // swizzle key: (row & 15) == (lr & 15) for both sub-tiles
-    // V^T (A operand of O^T) via ds_read_b64_tr_b16: 16-lane group g reads a 4-key x 16-d block;
-    // lane i of the group supplies row (i>>2), columns 4*(i&3)..+3 and receives column i.
-    const int vi = lane & 15;
-    const int vq = vi >> 2, vp = vi & 3;
-    const int vdh = (lane >> 4) & 1;          // which 16-wide half of the 32-d tile
-    // byte column inside the 256-B row for d-tile dt: (32*dt + 16*vdh + 4*vp) * 2 = 64*dt + 32*vdh + 8*vp
-    // swizzled: segment (dt ^ (key&3)) * 64 + 32*vdh + 8*vp ; key&3 == vq for every block (block bases are % 4 == 0)
-    int vcol[4];
+    for (int ks = 0; ks < 8; ++ks) ka[ks] = lds0 + lr * 256 + (((2 * ks + lh) ^ (lr & 15)) << 4);
+    // V^T (A operand of O^T) via ds_read_b64_tr_b16: 16-lane group g reads a 4-key x 16-d block; lane i of the group
+    // supplies row (i>>2), columns 4*(i&3)..+3 and receives column i.  Byte column inside the 256-B row for d-tile dt:
+    // 64*dt + 32*vdh + 8*vp, swizzled to segment (dt ^ (key&3)); key&3 == vq for every block (block bases are % 4 == 0).
+    uint32_t va[4];
+    {
+        const int vi = lane & 15;
+        const int vq = vi >> 2, vp = vi & 3;
+        const int vdh = (lane >> 4) & 1;          // which 16-wide half of the 32-d tile
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vcol[dt] = ((dt ^ vq) << 6) + 32 * vdh + 8 * vp;
-    const int vrow0 = (4 * lh + vq) * 256;    // + (32*kt2 + 16*s [+8]) * 256
+        for (int dt = 0; dt < 4; ++dt)
+            va[dt] = lds0 + NKB * KBYTES + (4 * lh + vq) * 256 + ((dt ^ vq) << 6) + 32 * vdh + 8 * vp;   // + (32*kt2 + 16*s [+8]) * 256
+    }
 
     f32x16_t acc[4];
 #pragma unroll
@@ -157,17 +189,32 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     f32x16_t s[2];
     bf16x8_t pb[2][2];
 
-    // S^T = K . Q^T from K buffer KBUF, then mask keys past Sk (last tile only)
-#define QK_PHASE(KBUF, T)                                                                                          \
+    // ---- phases, cut into fenced blocks: the fragment reads of one key half (kt2) go into a named block well ahead of the 8
+    //      MFMAs that consume it.  A K block and a V block of the same half have disjoint live ranges (32 shared VGPRs).
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+    // All LDS reads of the loop are inline asm with hand-counted lgkmcnt waits: with a DMA in flight hipcc puts a
+    // vmcnt(0) in front of every ds_read_b64_tr_b16 it knows about (the LDS-DMA vs LDS-read rule of its waitcnt pass), i.e.
+    // it would drain the tile prefetch.  LDS returns data in order, so "the fragment requested N reads ago is complete"
+    // is lgkmcnt(N) (field range 0..15).  A wait ties the fragment's registers ("+v") so that no consumer can be scheduled
+    // above it; sched_barrier fences keep the MFMAs (register-only, not ordered by a memory clobber) in their slots.
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define RD_K(KT2, KS, DST)                                                                                         \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ka[KS]), "i"((KT2) * 8192) : "memory")
+    // V fragment F = 4*sidx + dt of key half KT2: two transposed 4-key blocks (keys +0..3 and +8..11 of the 16-key step)
+#define RD_V(KT2, F, DST)                                                                                          \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                      \
+                 : "=&v"(DST.lo), "=&v"(DST.hi)                                                                    \
+                 : "v"(va[(F) & 3]), "i"((32 * (KT2) + 16 * ((F) >> 2)) * 256), "i"((32 * (KT2) + 16 * ((F) >> 2) + 8) * 256) \
+                 : "memory")
+#define WAIT_K(N, X) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(X) : "i"(N) : "memory")
+#define WAIT_V(N, X) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(X.lo), "+v"(X.hi) : "i"(N) : "memory")
+#define JOIN(X) __builtin_shufflevector(X.lo, X.hi, 0, 1, 2, 3, 4, 5, 6, 7)
+#define MFMA(A, B, C) ((ATT_ABL & 4) ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0))
+#define K_STEP(DELTA) do { _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) ka[ks] += (DELTA); } while (0)
+#define V_STEP(DELTA) do { _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) va[dt] += (DELTA); } while (0)
+    // mask keys past Sk (last tile only)
+#define QK_MASK(T)                                                                                                 \
     do {                                                                                                           \
-        const char* ks_ = smem + (KBUF) * KBYTES;                                                                  \
-        _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2) {                                                      \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kt2][r] = 0.f;                                        \
-            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                     \
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks_ + koff[kt2] + (((2 * ks + lh) ^ kx) << 4)); \
-                s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt2], 0, 0, 0);                     \
-            }                                                                                                      \
-        }                                                                                                          \
         if ((int64_t)((T) + 1) * KVT > Sk) {                                                                       \
             const int64_t kbase = (int64_t)(T) * KVT + 4 * lh;                                                     \
             _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2)                                                    \
@@ -205,8 +252,9 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2) {                                                      \
             float p[16];                                                                                           \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                       \
-                p[r] = (EXPV & 4) ? (s[kt2][r] * scale_log2e - mc) : __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);                                       \
-                ps4[r & 3] += p[r];                                                                                \
+                if (ATT_ABL & 1) { p[r] = s[kt2][r]; } else {                                                       \
+                p[r] = __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);                                       \
+                ps4[r & 3] += p[r]; }                                                                              \
             }                                                                                                      \
             _Pragma("unroll") for (int sidx = 0; sidx < 2; ++sidx) {                                               \
                 union { bf16x8_t v; uint32_t u[4]; } cv;                                                           \
@@ -217,66 +265,137 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);                                                            \
     } while (0)
 
-    // O^T += V^T . P^T from V buffer VBUF
-#define PV_PHASE(VBUF)                                                                                             \
-    do {                                                                                                           \
-        const char* vs_ = smem + (2 + (VBUF)) * KBYTES;                                                            \
-        _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2)                                                        \
-            _Pragma("unroll") for (int sidx = 0; sidx < 2; ++sidx) {                                               \
-                const char* vb = vs_ + vrow0 + (32 * kt2 + 16 * sidx) * 256;                                       \
-                _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                 \
-                    const bf16x4_t lo = ds_read_tr16(vb + vcol[dt]);                                               \
-                    const bf16x4_t hi = ds_read_tr16(vb + 8 * 256 + vcol[dt]);                                     \
-                    bf16x8_t vf;                                                                                   \
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];                                    \
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];                                    \
-                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt2][sidx], acc[dt], 0, 0, 0);        \
-                }                                                                                                  \
-            }                                                                                                      \
+    const int nt = (int)((Sk + KVT - 1) / KVT);
+    const int grp = wave >> 2;
+    // ---- prologue: tiles 0 and 1 landed and visible
+    if (nt == 1 && last_rows < KVT) CLAMP_LAST_TILE();
+    STAGE_TILE(0, 0, 0);
+    if (nt > 1) {
+        if (nt == 2 && last_rows < KVT) CLAMP_LAST_TILE();
+        STAGE_TILE(1, 1, 1);
+    }
+    DMA_WAIT(0);
+    BARRIER();
+    if (nt == 3 && last_rows < KVT) CLAMP_LAST_TILE();                // M(0) requests tile 2
+    if (grp == 1) BARRIER();                       // G1 runs one interval behind G0
+
+    bf16x8_t ka_[8], kb_[8];                       // K fragments of key half 0 / 1
+    struct vfrag_t { bf16x4_t lo, hi; } va_[8], vb_[8];   // V fragments of key half 0 / 1 (halves as the transposed reads deliver them)
+    bf16x8_t vc_[8];                               // first half of V[t], joined, carried from the end of S(t) into M(t+1)
+    int kbuf = 0, vbuf = 0;                        // t % NKB, t % NVB
+    int kreq = 2 % NKB, vreq = 2 % NVB;            // buffers of the tile that M(t) requests (t + 2)
+
+    // ---- M(t) = PV(t-1) . QK(t): four blocks of 8 MFMAs.  Every MFMA is followed, in its own issue shadow, by the fragment
+    //      read(s) that the MFMA one block later needs (a full block = 256 cycles of latency budget), and is preceded by the
+    //      counted wait for its own fragment: reads issued after fragment f of the running block = the rest of that block's
+    //      reads + what this block has requested so far.  va points at V[t-1] during PV0, at V[t] from QK1 on (stepped
+    //      during PV1); ka is stepped to K[t+1] during QK1.  One DMA piece of tile t+2 per block.
+#define STEP_PV0(F)                                                                           \
+    do {                                                                                      \
+        acc[(F) & 3] = MFMA(vc_[F], pb[0][(F) >> 2], acc[(F) & 3]);                           \
+        RD_V(1, F, vb_[F]);                                                                   \
+        FENCE();                                                                              \
+    } while (0)
+#define STEP_PV1(F, WITH_K)                                                                   \
+    do {                                                                                      \
+        WAIT_V((WITH_K) ? 14 - (F) : 14 - 2 * (F), vb_[F]);                                   \
+        FENCE();                                                                              \
+        acc[(F) & 3] = MFMA(JOIN(vb_[F]), pb[1][(F) >> 2], acc[(F) & 3]);                     \
+        if (WITH_K) RD_K(0, F, ka_[F]);                                                       \
+        FENCE();                                                                              \
+    } while (0)
+#define STEP_QK0(KS)                                                                          \
+    do {                                                                                      \
+        WAIT_K(7, ka_[KS]);                                                                   \
+        FENCE();                                                                              \
+        s[0] = (ATT_ABL & 8) ? s[0] : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka_[KS], qf[KS], s[0], 0, 0, 0); \
+        RD_K(1, KS, kb_[KS]);                                                                 \
+        FENCE();                                                                              \
+    } while (0)
+#define STEP_QK1(KS)                                                                          \
+    do {                                                                                      \
+        WAIT_K(7 + (KS), kb_[KS]);                                                            \
+        FENCE();                                                                              \
+        s[1] = (ATT_ABL & 8) ? s[1] : __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_[KS], qf[KS], s[1], 0, 0, 0); \
+        RD_V(0, KS, va_[KS]);                                                                 \
+        FENCE();                                                                              \
+    } while (0)
+#define ZERO_S(KT2) do { _Pragma("unroll") for (int r = 0; r < 16; ++r) s[KT2][r] = 0.f; } while (0)
+#define REQ_PIECE(P, T)                                                                       \
+    do {                                                                                      \
+        if (!(ATT_ABL & 16)) DMA_PIECE(P, min((T) + 2, nt - 1), kreq, vreq);                  \
+        FENCE();                                                                              \
+    } while (0)
+    // QK(t) blocks + end of M(t): the DMA of tile t+1 (requested in M(t-1), older than this segment's 4 pieces) has landed
+#define M_QK(T)                                                                               \
+    do {                                                                                      \
+        ZERO_S(0);                                                                            \
+        STEP_QK0(0); STEP_QK0(1); STEP_QK0(2); STEP_QK0(3);                                   \
+        REQ_PIECE(2, T);                                                                      \
+        STEP_QK0(4); STEP_QK0(5); STEP_QK0(6); STEP_QK0(7);                                   \
+        K_STEP(kbuf == NKB - 1 ? -(NKB - 1) * KBYTES : KBYTES);          /* K[t] -> K[t+1] */ \
+        kbuf = kbuf == NKB - 1 ? 0 : kbuf + 1;                                                \
+        ZERO_S(1);                                                                            \
+        STEP_QK1(0); STEP_QK1(1); STEP_QK1(2); STEP_QK1(3);                                   \
+        REQ_PIECE(3, T);                                                                      \
+        STEP_QK1(4); STEP_QK1(5); STEP_QK1(6); STEP_QK1(7);                                   \
+        QK_MASK(T);                                                                           \
+        kreq = kreq == NKB - 1 ? 0 : kreq + 1;                                                \
+        vreq = vreq == NVB - 1 ? 0 : vreq + 1;                                                \
+        if ((T) + 3 == nt - 1 && last_rows < KVT) CLAMP_LAST_TILE();    /* before M(t+1) requests the last tile */ \
+        FENCE();                                                                              \
+        if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);                                          \
+        DMA_WAIT(4);                                                                          \
+        BARRIER();                                                                            \
+    } while (0)
+    // ---- S(t): softmax only; the first V half of tile t (requested during QK1) is complete at its end
+#define S_SEGMENT()                                                                           \
+    do {                                                                                      \
+        SOFTMAX_PHASE();                                                                      \
+        FENCE();                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                   \
+                     : "+v"(va_[0].lo), "+v"(va_[0].hi), "+v"(va_[1].lo), "+v"(va_[1].hi), "+v"(va_[2].lo), "+v"(va_[2].hi), \
+                       "+v"(va_[3].lo), "+v"(va_[3].hi), "+v"(va_[4].lo), "+v"(va_[4].hi), "+v"(va_[5].lo), "+v"(va_[5].hi), \
+                       "+v"(va_[6].lo), "+v"(va_[6].hi), "+v"(va_[7].lo), "+v"(va_[7].hi) :: "memory"); \
+        _Pragma("unroll") for (int f = 0; f < 8; ++f) vc_[f] = JOIN(va_[f]);                  \
+        BARRIER();                                                                            \
     } while (0)
 
-    const int nt = (int)((Sk + KVT - 1) / KVT);
-    LOAD_TILE((int64_t)0);
-    WRITE_TILE(0, 0);
-    __syncthreads();
-
-    // The two waves that share a SIMD (w and w+4) run the SAME tile between two barriers but in rotated order:
-    //   group 0:  QK(t) . softmax(t) . PV(t)            group 1:  PV(t-1) . QK(t) . softmax(t)
-    // so after the barrier one wave's softmax (VALU) overlaps the other's MFMA phases instead of both contending for
-    // the matrix pipe and then both for the VALU.  V is triple-buffered (group 1 still reads V[t-1] while V[t+1] lands).
-    int vcur = 0;                                  // t % 3
-    if (wave < 4) {
-        for (int t = 0; t < nt; ++t) {
-            const int vnext = vcur == 2 ? 0 : vcur + 1;
-            if (!(EXPV & 2) && t + 1 < nt) LOAD_TILE((int64_t)(t + 1) * KVT);
-            QK_PHASE(t & 1, t);
-            SOFTMAX_PHASE();
-            PV_PHASE(vcur);
-            if (!(EXPV & 2) && t + 1 < nt) WRITE_TILE((t + 1) & 1, vnext);
-            if (!(EXPV & 1)) __syncthreads();
-            vcur = vnext;
-        }
-    } else {
-        int vprev = 2;
-        for (int t = 0; t < nt; ++t) {
-            const int vnext = vcur == 2 ? 0 : vcur + 1;
-            if (!(EXPV & 2) && t + 1 < nt) LOAD_TILE((int64_t)(t + 1) * KVT);
-            if (t > 0) PV_PHASE(vprev);
-            QK_PHASE(t & 1, t);
-            SOFTMAX_PHASE();
-            if (!(EXPV & 2) && t + 1 < nt) WRITE_TILE((t + 1) & 1, vnext);
-            if (!(EXPV & 1)) __syncthreads();
-            vprev = vcur;
-            vcur = vnext;
-        }
-        PV_PHASE(vprev);
+    // tile 0: M(0) = QK(0) only (peeled: the loop body then has ONE fragment history, no merge)
+    if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) RD_K(0, ks, ka_[ks]);
+    FENCE();
+    REQ_PIECE(0, 0);
+    REQ_PIECE(1, 0);
+    M_QK(0);
+    S_SEGMENT();
+    for (int t = 1; t < nt; ++t) {
+        if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
+        STEP_PV0(0); STEP_PV0(1); STEP_PV0(2); STEP_PV0(3);
+        REQ_PIECE(0, t);
+        STEP_PV0(4); STEP_PV0(5); STEP_PV0(6); STEP_PV0(7);
+        V_STEP(vbuf == NVB - 1 ? -(NVB - 1) * KBYTES : KBYTES);         // V[t-1] -> V[t] (all reads of V[t-1] are issued)
+        vbuf = vbuf == NVB - 1 ? 0 : vbuf + 1;
+        STEP_PV1(0, 1); STEP_PV1(1, 1); STEP_PV1(2, 1); STEP_PV1(3, 1);
+        REQ_PIECE(1, t);
+        STEP_PV1(4, 1); STEP_PV1(5, 1); STEP_PV1(6, 1); STEP_PV1(7, 1);
+        M_QK(t);
+        S_SEGMENT();
     }
+    // M(nt) = PV(nt-1)
+    if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
+    STEP_PV0(0); STEP_PV0(1); STEP_PV0(2); STEP_PV0(3); STEP_PV0(4); STEP_PV0(5); STEP_PV0(6); STEP_PV0(7);
+    STEP_PV1(0, 0); STEP_PV1(1, 0); STEP_PV1(2, 0); STEP_PV1(3, 0); STEP_PV1(4, 0); STEP_PV1(5, 0); STEP_PV1(6, 0); STEP_PV1(7, 0);
+    if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);
+    DMA_WAIT(0);                                   // (the clamped re-requests of the last tile: nothing may land after the epilogue took the LDS)
+    if (grp == 0) BARRIER();                       // balance G1's extra barrier
 
     // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l   (or the un-normalised partial when the keys are split)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int64_t qrow = q0 + lr;
-    if (qrow < Sq) {
-        if (nsplit > 1) {
+    if (nsplit > 1) {
+        if (qrow < Sq) {
             // partial layout: Opart[split][batch][q][heads*128] fp32, MLpart[split][batch][q][heads][2] = (m, l)
             const int nbatch = total / (nqb * heads * nsplit);
             const int64_t rowid = ((int64_t)split * nbatch + b) * Sq + qrow;
@@ -291,20 +410,52 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
                 float2* ml = reinterpret_cast<float2*>(MLpart) + rowid * heads + head;
                 *ml = make_float2(m_run, l_tot);
             }
-        } else {
-            const float inv = 1.0f / l_tot;
-            bf16_t* op = O + b * bso + qrow * ldo + (int64_t)head * 128 + 4 * lh;
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+#if ATT_EPI_LDS
+    // The lane owns 4 consecutive d of ONE query row per (dt, rg): stored directly that is 16 x 8 B per lane at a row
+    // stride (32 rows x 16 B per store instruction, partial lines).  Instead the wave's 32 x 128 tile goes through its own
+    // 8 KiB of the (now dead) K/V buffers - 16-byte chunk c of row r at chunk position c ^ (r & 15) - and leaves as whole
+    // rows: 16 lanes x 16 B = one 256-B row, 4 rows per store instruction.
+    __syncthreads();                               // group 1's last PV still read a V buffer
+    {
+        char* ob = smem + wave * 8192;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    uint2 o;
-                    o.x = pack_bf2(acc[dt][4 * rg + 0] * inv, acc[dt][4 * rg + 1] * inv);
-                    o.y = pack_bf2(acc[dt][4 * rg + 2] * inv, acc[dt][4 * rg + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rg) = o;
-                }
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 o;
+                o.x = pack_bf2(acc[dt][4 * rg + 0] * inv, acc[dt][4 * rg + 1] * inv);
+                o.y = pack_bf2(acc[dt][4 * rg + 2] * inv, acc[dt][4 * rg + 3] * inv);
+                *reinterpret_cast<uint2*>(ob + lr * 256 + (((4 * dt + rg) ^ (lr & 15)) << 4) + 8 * lh) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes, read back by other lanes
+        const int oc = lane & 15;
+        bf16_t* op = O + b * bso + (int64_t)head * 128 + oc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 4 * j + (lane >> 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(ob + row * 256 + ((oc ^ (row & 15)) << 4));
+            const int64_t qr = q0 + row;
+            if (qr < Sq) *reinterpret_cast<uint4*>(op + qr * ldo) = v;
         }
     }
+#else
+    if (qrow < Sq) {
+        bf16_t* op = O + b * bso + qrow * ldo + (int64_t)head * 128 + 4 * lh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 o;
+                o.x = pack_bf2(acc[dt][4 * rg + 0] * inv, acc[dt][4 * rg + 1] * inv);
+                o.y = pack_bf2(acc[dt][4 * rg + 2] * inv, acc[dt][4 * rg + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rg) = o;
+            }
+    }
+#endif
 }
 
 // merge the nsplit partials of one (row, head): O = sum_s w_s O_s / sum_s w_s l_s,  w_s = 2^((m_s - max m) * scale*log2e)
@@ -339,9 +490,9 @@ static int attention_launch(const void* q, const void* k, const void* v, void* o
                             int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv,
                             int64_t bso, float scale, int nsplit, void* workspace, void* stream) {
     DRN_CHECK_ARG(q && k && v && o && batch > 0 && heads > 0 && Sq >= 0 && Sk > 0 && nsplit >= 1);
-    DRN_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
-    DRN_CHECK_ARG(bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 4 == 0);
-    DRN_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 7) == 0);
+    DRN_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
+    DRN_CHECK_ARG(bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 8 == 0);
+    DRN_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 15) == 0);
     if (Sq == 0) return DRN_OK;
     int64_t kv_chunk = Sk;
     if (nsplit > 1) {

@@ -141,33 +141,42 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
         return;
     }
-    // ---- epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + r
+    // ---- epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = 16 j + 4*(lane>>4) + r; column tiles j = 2p / 2p+1 are
+    //      exchanged between lane rows fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 16 B (see gemm256.hip)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 16 + fr;
-        if (m >= M) continue;
+        const int64_t m_raw = m0 + wm * 64 + i * 16 + fr;
+        const bool m_ok = m_raw < M;
+        const int64_t m = m_ok ? m_raw : M - 1;
         const int64_t b = (EPI == DRN_EPI_GATE_RES) ? m / rpb : 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn * 64 + j * 16 + fq * 4;
-            float v[4];
+        for (int jp = 0; jp < 2; ++jp) {
+            uint2 o[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r]);
-            if (EPI == DRN_EPI_GELU) {
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * jp + h;
+                const int64_t n = n0 + wn * 64 + j * 16 + fq * 4;
+                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
-            } else if (EPI == DRN_EPI_GATE_RES) {
-                const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);
-                const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);
-                const float g[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
-                const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+                for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r]);
+                if (EPI == DRN_EPI_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                } else if (EPI == DRN_EPI_GATE_RES) {
+                    const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);
+                    const float g[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
+                    const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);
+                }
+                o[h].x = pack_bf2(v[0], v[1]);
+                o[h].y = pack_bf2(v[2], v[3]);
             }
-            uint2 o;
-            o.x = pack_bf2(v[0], v[1]);
-            o.y = pack_bf2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(C + m * ldc + n) = o;
+            const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+            const int64_t n8 = n0 + wn * 64 + jp * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+            if (m_ok) *reinterpret_cast<uint4*>(C + m * ldc + n8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
     }
 }

@@ -205,16 +205,18 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
             _Pragma("unroll") for (int h = 0; h < 2; ++h)                                               \
                 acc[mt][(OWN) + h] += *reinterpret_cast<const f32x4_t*>(mine + (mt * 2 + h) * 1024);    \
     } while (0)
-    // epilogue of the owned tiles: lane holds C[m][n..n+3]
+    // epilogue of the owned tiles: lane holds C[m][n..n+3] of both; the two column tiles are exchanged between lane rows
+    // fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 8 consecutive outputs, 16 B (see gemm256.hip)
 #define STORE_TILES(OWN)                                                                                \
     do {                                                                                                \
         _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                              \
-            const int64_t m = m0 + mt * 16 + fr;                                                        \
-            if (m >= M) continue;                                                                       \
+            const int64_t m_raw = m0 + mt * 16 + fr;                                                    \
+            const bool m_ok = m_raw < M;                                                                \
+            const int64_t m = m_ok ? m_raw : M - 1;                                                     \
             const int64_t b = (EPI == DRN_EPI_GATE_RES) ? m / rpb : 0;                                  \
+            uint2 o[2];                                                                                 \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                             \
                 const int64_t n = n0 + wn * 64 + ((OWN) + h) * 16 + fq * 4;                             \
-                if (n >= N) continue;                                                                   \
                 float v[4];                                                                             \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = rbf(acc[mt][(OWN) + h][r]);        \
                 if (EPI == DRN_EPI_GELU) {                                                              \
@@ -226,11 +228,14 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
                     const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};                \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);       \
                 }                                                                                       \
-                uint2 o;                                                                                \
-                o.x = pack_bf2(v[0], v[1]);                                                             \
-                o.y = pack_bf2(v[2], v[3]);                                                             \
-                *reinterpret_cast<uint2*>(C + m * ldc + n + c_tile_off) = o;                            \
+                o[h].x = pack_bf2(v[0], v[1]);                                                          \
+                o[h].y = pack_bf2(v[2], v[3]);                                                          \
             }                                                                                           \
+            const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);             \
+            const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);             \
+            const int64_t n8 = n0 + wn * 64 + (OWN) * 16 + (fq & 1) * 16 + (fq >> 1) * 8;               \
+            if (m_ok && n8 < N)                                                                         \
+                *reinterpret_cast<uint4*>(C + m * ldc + n8 + c_tile_off) = make_uint4(sx[0], sy[0], sx[1], sy[1]); \
         }                                                                                               \
     } while (0)
     if (grp == 0) {

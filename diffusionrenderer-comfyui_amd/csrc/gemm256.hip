@@ -206,20 +206,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();          // balance G1's extra barrier
 
-    // ---- epilogue: lane holds C[m][n..n+3]
+    // ---- epilogue.  After the MFMAs lane (fr, fq) holds C[m = ..+fr][n..n+3] for n = 16 nt + 4 fq: stored as it stands that
+    //      is 32 x 8 B per lane, 32 B contiguous per row and instruction (store-issue bound, partial lines).  The two column
+    //      tiles nt = 0 / 1 are therefore exchanged between the lane rows fq = 2k and 2k+1 (v_permlane16_swap: odd rows of the
+    //      first operand <-> even rows of the second), after which a lane owns 8 consecutive outputs:
+    //      fq 0: n 0..7, fq 1: n 16..23, fq 2: n 8..15, fq 3: n 24..31  ->  16 x 16-B stores, 64 B contiguous per row.
+    //      Partners share fr, i.e. the same output row, so row validity is identical on both sides of a swap; every lane
+    //      executes the swaps (rows past M compute on a clamped row and are not stored).
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + fr;
-            if (m >= M) continue;
+            const int64_t m_raw = m0 + i * 128 + wr * 64 + mt * 16 + fr;
+            const bool m_ok = m_raw < M;
+            const int64_t m = m_ok ? m_raw : M - 1;
             const int64_t b = (EPI == DRN_EPI_GATE_RES) ? m / rpb : 0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                uint2 o[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + fq * 4;
-                    if (n >= N) continue;
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][mt][j][nt][r]);
@@ -234,11 +241,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);
                     }
-                    uint2 o;
-                    o.x = pack_bf2(v[0], v[1]);
-                    o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(C + m * ldc + n + c_tile_off) = o;
+                    o[nt].x = pack_bf2(v[0], v[1]);
+                    o[nt].y = pack_bf2(v[2], v[3]);
                 }
+                const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+                const int64_t n8 = n0 + j * 128 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+                if (m_ok && n8 < N)
+                    *reinterpret_cast<uint4*>(C + m * ldc + n8 + c_tile_off) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
         }
 }
 

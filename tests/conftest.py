@@ -28,6 +28,18 @@ def gpu():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(scope="session")
+def full28_dit(pkg, gpu):
+    """The 28-block, 7.2 B-parameter inverse-renderer DiT with synthetic weights, built once per session (14.5 GB of HBM)."""
+    import torch
+    net = tiny_net(pkg, 4096, 28, 32)
+    sd = pkg.synthetic_weights.synth_state_dict(net, torch.bfloat16, device=gpu)
+    dit = pkg.dit_engine.HipDiT(net, sd, device=gpu)
+    del sd
+    torch.cuda.empty_cache()
+    return dit
+
+
 def load_golden(name):
     from safetensors import safe_open
     path = os.path.join(GOLDEN, name)

@@ -183,19 +183,68 @@ def _attn_ref(q, k, v, heads):
     kh = k.float().view(B, -1, heads, 128).transpose(1, 2)
     vh = v.float().view(B, -1, heads, 128).transpose(1, 2)
     s = qh @ kh.transpose(-1, -2) / math.sqrt(128)
-    o = torch.softmax(s, -1) @ vh
+    p = torch.softmax(s, -1)
+    o = p @ vh
+    _attn_ref.mag = ((p * p) @ (vh * vh)).sqrt().transpose(1, 2).reshape(B, Sq, HD)    # |terms| the output was summed from
     return o.transpose(1, 2).reshape(B, Sq, HD)
 
 
-@pytest.mark.parametrize("heads,Sq,Sk", [(2, 256, 256), (2, 128, 128), (4, 300, 300), (1, 513, 77), (32, 256, 1024)])
+# Measured on MI355X (round 2, printed by every test below): rel-L2 against the fp32 answer 2.4e-3 .. 2.9e-3 - bf16 output
+# rounding alone is 1.7e-3 (uniform relative error of 2^-9 / sqrt 3 ... 2^-8 / sqrt 3), the rest is P rounded to bf16 for the PV
+# MFMA (the reference's SDPA does the same); against the fp32 answer ROUNDED to bf16: <= 2 bf16 ulp everywhere.
+ATTN_REL_L2 = 3.6e-3          # 1.25 x the largest measured value
+
+
+def _attn_check(out, ref, tag, rel=ATTN_REL_L2, max_ulp=2, frac_exact=0.5):
+    """out bf16 vs fp32 reference (call right after _attn_ref): rel-L2, and distance to the reference rounded to bf16 in bf16
+    ulps of max(|o|, sqrt(sum_k p_k^2 v_k^2)) - the output is a sum of terms p_k v_k with P rounded to bf16 for the PV product
+    (as in the reference's SDPA), so where the terms cancel the rounding error scales with the terms, not with the sum."""
+    e = rel_l2(out, ref)
+    r16 = ref.to(BF)
+    mag = _attn_ref.mag.to(out.device)
+    o, r = out.float(), r16.float()
+    ulp = torch.maximum(torch.maximum(r.abs(), o.abs()), mag) * 2.0 ** -7
+    worst = (o - r).abs() / ulp.clamp_min(1e-30)
+    exact = (out == r16).float().mean().item()
+    print(f"attention {tag}: rel-L2 {e:.3e}  max|diff| {(o - ref.float()).abs().max().item():.3e}  worst {worst.max().item():.2f} ulp  "
+          f"exact {exact:.4f}")
+    assert e < rel, (tag, e)
+    ok, msg = ulp_diff_ok(out, r16, max_ulp=max_ulp, frac_exact=frac_exact, atol_rel=0.0, mag=mag)
+    assert ok, (tag, msg)
+
+
+@pytest.mark.parametrize("heads,Sq,Sk", [(2, 256, 256), (2, 128, 128), (4, 300, 300), (1, 513, 77), (32, 256, 1024), (2, 512, 4160)])
 def test_attention_matches_fp32(pkg, gpu, heads, Sq, Sk):
     q = rnd((1, Sq, heads * 128), gpu, seed=29)
     k = rnd((1, Sk, heads * 128), gpu, seed=30)
     v = rnd((1, Sk, heads * 128), gpu, seed=31)
     out = pkg.native.attention(q, k, v, heads=heads)
+    _attn_check(out, _attn_ref(q, k, v, heads), f"h{heads} Sq{Sq} Sk{Sk}")
+
+
+def test_attention_exact_integers_asymmetric(pkg, gpu):
+    """Small-integer Q/K/V with a softmax that is exactly one-hot (one key per query scores far above the rest): O must be
+    that key's V row bit for bit - catches any permutation slip in the K / V^T fragment order, the DMA swizzles and the
+    LDS-transposed epilogue (asymmetric data: every row and column differs)."""
+    heads, S = 2, 320
+    D = heads * 128
+    q = torch.zeros((1, S, D), dtype=BF, device=gpu)
+    k = torch.zeros((1, S, D), dtype=BF, device=gpu)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(5)).to(gpu)
+    cols = torch.arange(S, device=gpu) % 128
+    for h in range(heads):
+        # query i matches key perm[i]: both carry 40 at column (perm[i] % 128) of head h, plus a tag that separates keys
+        # sharing that column
+        k[0, torch.arange(S, device=gpu), h * 128 + cols] = 40.0
+        k[0, torch.arange(S, device=gpu), h * 128 + (cols + 1 + torch.arange(S, device=gpu) // 128) % 128] = 24.0
+        q[0, torch.arange(S, device=gpu), h * 128 + cols[perm]] = 40.0
+        q[0, torch.arange(S, device=gpu), h * 128 + (cols[perm] + 1 + perm // 128) % 128] = 24.0
+    v = (torch.arange(S * D, device=gpu).reshape(1, S, D) % 251 - 125).to(BF)
+    out = pkg.native.attention(q, k, v, heads=heads)
     ref = _attn_ref(q, k, v, heads)
-    assert rel_l2(out, ref) < 4e-3
-    assert (out.float() - ref).abs().max().item() < 0.03
+    # (the other keys weigh 2^-73: exact up to that, also where V is 0)
+    assert (out.float() - ref).abs().max().item() < 1e-18
+    assert (out.float() - v[:, perm].float()).abs().max().item() < 1e-18, "softmax is one-hot here: O[i] == V[perm[i]]"
 
 
 def test_attention_strided_qkv_buffer(pkg, gpu):
@@ -204,7 +253,7 @@ def test_attention_strided_qkv_buffer(pkg, gpu):
     qkv = rnd((S, 3 * D), gpu, seed=32)
     q, k, v = (qkv[:, i * D:(i + 1) * D].unsqueeze(0) for i in range(3))
     out = pkg.native.attention(q, k, v, heads=heads)
-    assert rel_l2(out, _attn_ref(q, k, v, heads)) < 4e-3
+    _attn_check(out, _attn_ref(q, k, v, heads), "strided qkv")
 
 
 def test_attention_online_softmax_rescale_spike(pkg, gpu):
@@ -216,9 +265,7 @@ def test_attention_online_softmax_rescale_spike(pkg, gpu):
     k[0, 400] = (q[0, 17].float() * 40).to(BF)       # score jumps by a large margin in tile 6
     k[0, 130] = (q[0, 200].float() * 25).to(BF)
     out = pkg.native.attention(q, k, v, heads=heads)
-    ref = _attn_ref(q, k, v, heads)
-    assert rel_l2(out, ref) < 4e-3
-    assert (out.float() - ref).abs().max().item() < 0.03
+    _attn_check(out, _attn_ref(q, k, v, heads), "rescale spike")
 
 
 def test_attention_large_scores_no_overflow(pkg, gpu):
@@ -228,7 +275,8 @@ def test_attention_large_scores_no_overflow(pkg, gpu):
     v = rnd((1, S, heads * 128), gpu, seed=38)
     out = pkg.native.attention(q, k, v, heads=heads)
     assert torch.isfinite(out.float()).all()
-    assert rel_l2(out, _attn_ref(q, k, v, heads)) < 6e-3
+    # scores of +-70: a near one-hot softmax amplifies the bf16 rounding of P on the few surviving keys
+    _attn_check(out, _attn_ref(q, k, v, heads), "large scores", rel=6e-3, max_ulp=3, frac_exact=0.4)
 
 
 # ------------------------------------------------------------------------------------------------ index ops (bit-exact)
@@ -300,20 +348,22 @@ def test_postprocess_all_bf16_values(pkg, gpu):
                                        (4096, 1024, 1024, 2)])
 def test_gemm256_kernel(pkg, gpu, M, N, K, epi, tile=1):
     a, w = rnd((M, K), gpu, seed=50), rnd((N, K), gpu, K ** -0.5, seed=51)
-    pkg.native.load_library().drn_gemm_force_tile(tile)
     lin = (a.float() @ w.float().t()).to(BF)
     mag = None
-    if epi == 0:
-        out, ref = pkg.native.gemm(a, w), lin
-    elif epi == 1:
-        out, ref = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GELU), F.gelu(lin.cpu()).to(gpu)
-    else:
-        x, gate = rnd((M, N), gpu, seed=52), rnd((1, N), gpu, 0.5, seed=53)
-        ref = x + gate * lin
-        mag = torch.maximum(x.abs(), (gate * lin).abs())
-        out = x.clone()
-        pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out)
-    pkg.native.load_library().drn_gemm_force_tile(-1)
+    pkg.native.load_library().drn_gemm_force_tile(tile)
+    try:
+        if epi == 0:
+            out, ref = pkg.native.gemm(a, w), lin
+        elif epi == 1:
+            out, ref = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GELU), F.gelu(lin.cpu()).to(gpu)
+        else:
+            x, gate = rnd((M, N), gpu, seed=52), rnd((1, N), gpu, 0.5, seed=53)
+            ref = x + gate * lin
+            mag = torch.maximum(x.abs(), (gate * lin).abs())
+            out = x.clone()
+            pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out)
+    finally:
+        pkg.native.load_library().drn_gemm_force_tile(-1)
     ok, msg = ulp_diff_ok(out, ref, max_ulp=2, frac_exact=0.97, mag=mag)
     assert ok, msg
 
@@ -390,8 +440,10 @@ def test_gemm144_identity_and_choice(pkg, gpu):
     a = torch.eye(M, K, dtype=BF, device=gpu)
     w = (torch.arange(N * K, device=gpu).reshape(N, K) % 251).to(BF)
     lib.drn_gemm_force_tile(2)
-    out = pkg.native.gemm(a, w)
-    lib.drn_gemm_force_tile(-1)
+    try:
+        out = pkg.native.gemm(a, w)
+    finally:
+        lib.drn_gemm_force_tile(-1)
     ref = torch.zeros(M, N, dtype=BF, device=gpu)
     ref[:K] = w.t()[:K]
     assert torch.equal(out, ref)
@@ -438,7 +490,8 @@ def test_attention_splitkv_matches_single_pass(pkg, gpu, heads, Sq, Sk, ns):
     one = pkg.native.attention(q, k, v, heads=heads, kv_splits=1)
     split = pkg.native.attention(q, k, v, heads=heads, kv_splits=ns)
     ref = _attn_ref(q, k, v, heads)
-    assert rel_l2(split, ref) < 4e-3 and rel_l2(one, ref) < 4e-3
+    _attn_check(one, ref, f"single pass Sk{Sk}")
+    _attn_check(split, ref, f"split-KV x{ns} Sk{Sk}")
     assert (split.float() - one.float()).abs().max().item() < 0.02
 
 
@@ -453,7 +506,7 @@ def test_attention_planned_tail_matches_single_pass(pkg, gpu):
     one = pkg.native.attention(q, k, v, heads=heads, kv_splits=1)
     assert torch.equal(auto[:, :2048], one[:, :2048])                  # the unsplit part is the same launch arithmetic
     assert (auto.float() - one.float()).abs().max().item() < 0.02
-    assert rel_l2(auto, _attn_ref(q, k, v, heads)) < 4e-3
+    _attn_check(auto, _attn_ref(q, k, v, heads), "planned tail")
 
 
 def test_pick_kv_splits(pkg):

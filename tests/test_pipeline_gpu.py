@@ -61,6 +61,41 @@ def test_generate_video_matches_reference_pipeline(pkg, gpu, fixture, tag):
     assert torch.equal(model.scheduler.sigmas, gold_sigmas(steps))
 
 
+def test_full_width_4step_pipeline_matches_reference_g4(pkg, gpu, full28_dit):
+    """SURVEY 8c G4 / BASELINE config 1 end to end: the 7.2 B-parameter model, 1 frame 256 x 256, 4 Euler steps, guidance 0,
+    normal pass, through generate_video with the x_T the reference drew - against the reference pipeline's own uint8 video and
+    against the trajectory re-traced by the oracle (bf16 = what the reference computes, fp32 network = the exact answer)."""
+    gold, meta = load_golden("sampler_full28_cfg1_g4.safetensors")
+    steps = int(meta["steps"])
+    cfg = pkg.diffusion_renderer_config.get_inverse_renderer_config()
+    cfg["net"] = dict(full28_dit.net)
+    model = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(cfg, device=gpu)
+    model.net = full28_dit                                   # weights already repacked (conftest.full28_dit)
+    p = pkg.diffusion_renderer_pipeline.CleanDiffusionRendererPipeline(
+        "/nonexistent", "x.pt", model_type=None, vae_instance=StubVAE(), model_instance=model, guidance=0.0, num_steps=steps)
+    p.device = gpu
+    p.set_model_type("inverse")
+    rgb = pkg.synthetic_weights.synth_tensor("g4.rgb", (1, 3, 1, 256, 256), torch.float32, scale=1.0)
+    ci = torch.full((1, 1), int(meta["context_index"]), dtype=torch.long)
+    batch = {"rgb": rgb, "video": rgb, "context_index": ci}
+    video = p.generate_video(batch, normalize_normal=True, seed=int(meta["seed"]), init_noise=gold["xT"])
+    ref = gold["video_u8"].numpy()
+    assert video.shape == ref.shape and video.dtype == ref.dtype
+    x0 = model.generate_samples_from_batch(dict(p._move_to_device(batch)), guidance=0.0, seed=int(meta["seed"]),
+                                           state_shape=list(gold["xT"].shape[1:]), num_steps=steps, init_noise=gold["xT"]).cpu()
+    exact = gold["x0.fp32net"].float()
+    e_hip, e_ref = rel_l2(x0, exact), rel_l2(gold["x0"], exact)
+    from oracle import dit_oracle as O
+    u8_32 = O.postprocess(StubVAE().decode(gold["x0.fp32net"] / 0.5), True).numpy()
+    d_hip = abs(video.astype(int) - u8_32.astype(int))
+    d_ref = abs(ref.astype(int) - u8_32.astype(int))
+    print(f"g4: x0 rel-L2 vs fp32-network trajectory: hip {e_hip:.3e}, reference-bf16 {e_ref:.3e}; uint8 mean |diff|: hip "
+          f"{d_hip.mean():.4f} (max {d_hip.max()}), reference {d_ref.mean():.4f} (max {d_ref.max()}); hip vs reference "
+          f"{abs(video.astype(int) - ref.astype(int)).mean():.4f}")
+    assert e_hip <= 1.5 * e_ref + 1e-3
+    assert d_hip.mean() <= 1.5 * d_ref.mean() + 0.25
+
+
 def gold_sigmas(n):
     from oracle import dit_oracle as O
     return O.edm_sigmas(n)
