@@ -18,6 +18,8 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -94,25 +96,99 @@ def cpu_baseline(pkg, S_full, budget_s=40.0):
     return {"value": 1.0 / (28.0 * t_blk), "unit": "steps/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+CONFIGS = {   # BASELINE.json configs that fit one node: (frames, height, width, default steps, default warm-up)
+    "cfg1": (1, 256, 256, 4, 1),       # 1 f 256^2: S = 256 tokens, a forward is a 14.5 GB weight stream (HBM roofline)
+    "cfg2": (9, 512, 512, 5, 1),       # nearest legal clip to "8 frames 512^2" (SURVEY F11): latent (2,64,64), S = 2048
+    "cfg2a": (8, 512, 512, 5, 1),      # the reference's own arithmetic for 8 frames: latent (1,64,64), S = 1024
+    "cfg3": (57, 576, 1024, 3, 1),     # the headline: full Cosmos clip, S = 18 432
+}
+PROBE_FAILED_RC = 75          # a rank's RCCL all-to-all probe failed: the launcher starts a FRESH run with the all-gather exchange
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` (how the driver calls it): start N ranks as a CHILD torch.distributed.run, relay rank 0's JSON
+    line and the exit code.  Runs before anything touches the GPU; never an exec (gpurun forbids exec after GPU init and a
+    child keeps this process free to retry).  If a rank reports that the all-to-all exchange cannot run on this RCCL build
+    (exit code PROBE_FAILED_RC), ONE fresh run is started with DRN_SP_EXCHANGE=gather - a communicator is not reused after a
+    failed collective."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for attempt in (0, 1):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = None
+        for ln in proc.stdout.splitlines():
+            t = ln.strip()
+            if t.startswith("{") and '"metric"' in t:
+                line = t
+            elif t:
+                print(t, file=sys.stderr, flush=True)
+        if line is not None and proc.returncode == 0:
+            print(line, flush=True)
+            return 0
+        if attempt == 0 and env.get("DRN_SP_EXCHANGE", "auto") != "gather":
+            print(f"[bench] {n}-rank run ended with rc {proc.returncode}; one fresh run with DRN_SP_EXCHANGE=gather", file=sys.stderr, flush=True)
+            env["DRN_SP_EXCHANGE"] = "gather"
+            continue
+        return proc.returncode or 1
+    return 1
+
+
+def dry_run(args, world, rank):
+    """Launcher rehearsal on CPU (tests/test_bench_launcher.py): gloo rendezvous at 127.0.0.1, a barrier, a MAX all-reduce and
+    rank 0's JSON line - everything bench.py does around the timed region except the GPU work itself."""
+    import torch.distributed as dist
+    if world > 1 or "WORLD_SIZE" in os.environ:
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "denoising_steps_per_sec", "value": 0.0, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "rccl_ranks": world}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=57)
-    ap.add_argument("--height", type=int, default=576)
-    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3", help="BASELINE.json config (default: the headline cfg3)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--blocks", type=int, default=28, help="debug only; the headline number needs 28")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tokenizer", action="store_true", help="skip the (untimed) tokenizer encode/decode leg")
     ap.add_argument("--no-cfg", action="store_true", help="skip the secondary guidance-2.0 (cond + uncond) figure")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU (gloo): no GPU work")
     args = ap.parse_args()
+    cf, ch, cw, cs, cwu = CONFIGS[args.config]
+    args.frames = cf if args.frames is None else args.frames
+    args.height = ch if args.height is None else args.height
+    args.width = cw if args.width is None else args.width
+    args.steps = cs if args.steps is None else args.steps
+    args.warmup = cwu if args.warmup is None else args.warmup
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # before any GPU call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -120,23 +196,20 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
-        # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step; if this build of RCCL
-        # cannot run the all-to-all, fall back to the all-gather exchange instead of losing the run
+        # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step
         probe = torch.zeros(world * 1024, dtype=torch.bfloat16, device=dev)
         dist.all_gather_into_tensor(torch.empty(world * 1024, dtype=torch.bfloat16, device=dev), probe[:1024].contiguous())
         torch.cuda.synchronize()
         if os.environ.get("DRN_SP_EXCHANGE", "auto") != "gather":
-            ok = torch.ones(1, device=dev)
+            # the exchange this run will use, tried once before anything is timed.  If this RCCL build cannot run it the
+            # process group is NOT reused (a communicator is unreliable after a failed collective): every rank that sees
+            # the failure exits with PROBE_FAILED_RC and the launcher starts a fresh run with the all-gather exchange
             try:
                 dist.all_to_all_single(torch.empty_like(probe), probe)
                 torch.cuda.synchronize()
-            except Exception as e:                                       # noqa: BLE001 - any transport error means "use gather"
-                print(f"[bench] rank {rank}: all_to_all_single failed ({type(e).__name__}: {e}); using the all-gather exchange",
-                      file=sys.stderr, flush=True)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # every rank must take the same path
-            if ok.item() == 0:
-                os.environ["DRN_SP_EXCHANGE"] = "gather"
+            except Exception as e:                                       # noqa: BLE001 - any transport error
+                print(f"[bench] rank {rank}: all_to_all_single failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+                os._exit(PROBE_FAILED_RC)
 
     pkg = load_package()
     N = pkg.native

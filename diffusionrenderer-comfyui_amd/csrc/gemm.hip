@@ -262,53 +262,9 @@ extern "C" int drn_gemm_tile_choice(int64_t M, int64_t N) { return pick_gemm_til
 // blk = {a_shift, a_block_stride, c_shift, c_block_stride}; shift 62 = plain layout
 static const int64_t kPlain[4] = {62, 0, 62, 0};
 
-static int gemm_impl(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                     int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
-                     int64_t ldr, int64_t rows_per_batch, void* stream, const int64_t* blk) {
-    DRN_CHECK_ARG(A && W && C && M >= 0 && N > 0 && K > 0);
-    DRN_CHECK_ARG(K % BK == 0 && N % BN == 0);
-    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ldw >= K);
-    DRN_CHECK_ARG((blk[0] != 62 || lda >= K) && (blk[2] != 62 || ldc >= N));
-    DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0);
-    if (epilogue == DRN_EPI_GATE_RES)
-        DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
-    if (M == 0) return DRN_OK;
-    if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
-    double cost_all = 0.0;
-    const int tile = pick_gemm_tile(M, N, &cost_all);
-    const bool blocked = blk[0] != 62 || blk[2] != 62;
-    if (blocked && tile == 0) return DRN_EINVAL;           // the 128x128 kernel has no blocked layouts (callers regroup instead)
-    // A fractional last round of 256^2 workgroups idles CUs (72 x 16 tiles = 4.5 rounds cost 5).  Rows are independent, so the
-    // tile rows that fill whole rounds run as one launch and the remaining rows as a second one with the tile that suits
-    // them (DRN_GEMM_TAIL=0 switches this off).
-    static int tail_mode = -1;
-    if (tail_mode < 0) {
-        const char* e = getenv("DRN_GEMM_TAIL");
-        tail_mode = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (tile == 1 && tail_mode == 1 && g_force_tile < 0) {
-        const int64_t tm = (M + 255) / 256, tn = N / 256;
-        const int64_t rounds = tm * tn / 256, rem = tm * tn % 256;
-        const int64_t tm_main = rounds * 256 / tn;
-        const int64_t M_main = tm_main * 256;
-        const bool gate_ok = epilogue != DRN_EPI_GATE_RES || rows_per_batch >= M || M_main % rows_per_batch == 0;
-        if (rounds >= 1 && rem != 0 && tm_main >= 1 && tm_main < tm && gate_ok) {
-            double cost_tail = 0.0;
-            const int tail_tile = pick_gemm_tile(M - M_main, N, &cost_tail);
-            if (blocked && tail_tile == 0) cost_tail = 1e30;
-            const double cost_split = (double)((tm_main * tn + 255) / 256) + cost_tail + 0.02;
-            if (cost_split < cost_all - 0.05) {
-                const int rc = drn_gemm256_dispatch(A, W, C, M_main, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr,
-                                                    rows_per_batch, stream, blk);
-                if (rc != DRN_OK) return rc;
-                const bf16_t* gate_t = (const bf16_t*)gate;
-                if (epilogue == DRN_EPI_GATE_RES && rows_per_batch < M) gate_t += (M_main / rows_per_batch) * N;
-                return gemm_impl((const bf16_t*)A + M_main * lda, W, (bf16_t*)C + M_main * ldc, M - M_main, N, K, lda, ldw, ldc,
-                                 epilogue, gate_t, residual ? (const bf16_t*)residual + M_main * ldr : nullptr, ldr,
-                                 rows_per_batch, stream, blk);
-            }
-        }
-    }
+static int gemm_launch_tile(int tile, const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                            int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr,
+                            int64_t rows_per_batch, void* stream, const int64_t* blk) {
     if (tile == 1)
         return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
     if (tile == 2)
@@ -327,6 +283,86 @@ static int gemm_impl(const void* A, const void* W, void* C, int64_t M, int64_t N
     }
 #undef ARGS
     return drn_launch_status();
+}
+
+// How the rows of ONE clip (M rows, one gate row) are covered: the tile kernel for the rows that fill whole rounds of 256^2
+// workgroups, and - when the last round would be fractional (72 x 16 tiles = 4.5 rounds cost 5) - a second launch for the
+// remaining rows with the tile that suits them (DRN_GEMM_TAIL=0 switches the split off).  Returns the row count of the first
+// launch (M = no split) and its tile.
+static int64_t gemm_plan_rows(int64_t M, int64_t N, bool blocked, int* tile_out) {
+    double cost_all = 0.0;
+    const int tile = pick_gemm_tile(M, N, &cost_all);
+    *tile_out = tile;
+    static int tail_mode = -1;
+    if (tail_mode < 0) {
+        const char* e = getenv("DRN_GEMM_TAIL");
+        tail_mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (tile != 1 || tail_mode != 1 || g_force_tile >= 0) return M;
+    const int64_t tm = (M + 255) / 256, tn = N / 256;
+    const int64_t rounds = tm * tn / 256, rem = tm * tn % 256;
+    const int64_t tm_main = rounds * 256 / tn;
+    if (rounds < 1 || rem == 0 || tm_main < 1 || tm_main >= tm) return M;
+    const int64_t M_main = tm_main * 256;
+    double cost_tail = 0.0;
+    const int tail_tile = pick_gemm_tile(M - M_main, N, &cost_tail);
+    if (blocked && tail_tile == 0) cost_tail = 1e30;
+    const double cost_split = (double)((tm_main * tn + 255) / 256) + cost_tail + 0.02;
+    return cost_split < cost_all - 0.05 ? M_main : M;
+}
+
+// one clip (or a plain problem): rows_per_batch >= M here
+static int gemm_clip(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                     int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, void* stream,
+                     const int64_t* blk) {
+    const bool blocked = blk[0] != 62 || blk[2] != 62;
+    int tile = 0;
+    const int64_t M_main = gemm_plan_rows(M, N, blocked, &tile);
+    if (blocked && tile == 0) return DRN_EINVAL;           // the 128x128 kernel has no blocked layouts (callers regroup instead)
+    if (M_main == M)
+        return gemm_launch_tile(tile, A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, M, stream, blk);
+    const int rc = gemm_launch_tile(1, A, W, C, M_main, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, M_main, stream, blk);
+    if (rc != DRN_OK) return rc;
+    return gemm_clip((const bf16_t*)A + M_main * lda, W, (bf16_t*)C + M_main * ldc, M - M_main, N, K, lda, ldw, ldc, epilogue, gate,
+                     residual ? (const bf16_t*)residual + M_main * ldr : nullptr, ldr, stream, blk);
+}
+
+static int gemm_impl(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                     int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
+                     int64_t ldr, int64_t rows_per_batch, void* stream, const int64_t* blk) {
+    DRN_CHECK_ARG(A && W && C && M >= 0 && N > 0 && K > 0);
+    DRN_CHECK_ARG(K % BK == 0 && N % BN == 0);
+    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ldw >= K);
+    DRN_CHECK_ARG((blk[0] != 62 || lda >= K) && (blk[2] != 62 || ldc >= N));
+    DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0);
+    if (epilogue == DRN_EPI_GATE_RES)
+        DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
+    if (M == 0) return DRN_OK;
+    if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
+    // B clips stacked along the rows (rows_per_batch = rows of one clip): the tile kernel and the tail split decide the
+    // accumulation order of an output element, so both are chosen from ONE clip's rows - a clip then gets the same bits
+    // whatever it is batched with (the reference steps its G-buffer passes / CFG halves one clip at a time, nodes.py:187-213).
+    const bool batched = rows_per_batch > 0 && rows_per_batch < M && M % rows_per_batch == 0 && blk[0] == 62 && blk[2] == 62;
+    if (!batched) {
+        if (epilogue == DRN_EPI_GATE_RES && rows_per_batch < M) {
+            // ragged batches (the last one shorter): one launch with the tile of the whole problem, gates by row / rows_per_batch
+            int tile = 0;
+            (void)gemm_plan_rows(M, N, blk[0] != 62 || blk[2] != 62, &tile);
+            return gemm_launch_tile(tile, A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
+        }
+        return gemm_clip(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, stream, blk);
+    }
+    const int64_t Mb = rows_per_batch, nb = M / Mb;
+    int tile = 0;
+    if (gemm_plan_rows(Mb, N, false, &tile) == Mb)          // one kernel covers a clip: one launch covers them all
+        return gemm_launch_tile(tile, A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, Mb, stream, blk);
+    for (int64_t b = 0; b < nb; ++b) {
+        const int rc = gemm_clip((const bf16_t*)A + b * Mb * lda, W, (bf16_t*)C + b * Mb * ldc, Mb, N, K, lda, ldw, ldc, epilogue,
+                                 epilogue == DRN_EPI_GATE_RES ? (const bf16_t*)gate + b * N : nullptr,
+                                 residual ? (const bf16_t*)residual + b * Mb * ldr : nullptr, ldr, stream, blk);
+        if (rc != DRN_OK) return rc;
+    }
+    return DRN_OK;
 }
 
 extern "C" int drn_gemm_bf16(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -372,7 +408,8 @@ extern "C" int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int spl
 }
 
 // how many K splits keep the CUs busy for an [M, N, K] product (1 = none): at most half of the 512 workgroup slots filled by
-// 128^2 tiles, at most 512 workgroups after the split and at least 16 K steps left per split
+// 128^2 tiles, at most 512 workgroups after the split and at least 16 K steps left per split.  Callers with B clips stacked
+// along the rows pass ONE clip's rows (the split changes the summation order: it must not depend on the batch)
 extern "C" int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
     if (N % BN != 0 || K % BK != 0 || M <= 0) return 1;
     if (pick_gemm_tile(M, N) != 0) return 1;

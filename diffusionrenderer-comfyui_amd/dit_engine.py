@@ -366,10 +366,11 @@ class HipDiT:
             # shift | scale rows per clip for the batched LayerNorm pass: [sites, 2, B, D] (one sigma -> B equal rows)
             modB = mod[:, :2 * D].reshape(-1, 2, 1, D).expand(-1, 2, B, D).contiguous()
             modfB = modf.view(2, 1, D).expand(2, B, D).contiguous()
+            gateB = mod[:, 2 * D:].reshape(-1, 1, D).expand(-1, B, D).contiguous()     # one gate row per clip: [sites, B, D]
 
         # the latent is tiny: every rank patchifies it all and keeps its own token band
         P = N.patchify_concat(x, cond, self.with_mask, self.pt, self.ps, self.kpad)
-        N.gemm(plan.band(P) if B == 1 else P, self.w_patch, out=X)
+        N.gemm(plan.band(P) if B == 1 else P, self.w_patch, out=X, rows_per_batch=rows)
 
         pending = None
         site = 0
@@ -394,7 +395,7 @@ class HipDiT:
                 if sb["kind"] == "fa":
                     if self.exchange == "none":
                         QKV = ws["qkv"]
-                        N.gemm(Hb, sb["wqkv"], out=QKV)
+                        N.gemm(Hb, sb["wqkv"], out=QKV, rows_per_batch=rows)
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
                         N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads, tokens_per_batch=S)
                     elif self.exchange == "a2a":
@@ -455,10 +456,12 @@ class HipDiT:
                     else:
                         Q3 = QKV.view(B, S, 3 * D)
                         N.attention(Q3[:, :, :D], Q3[:, :, D:2 * D], Q3[:, :, 2 * D:], out=O.view(B, S, D), heads=self.heads)
-                    N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
+                    N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gateB[site - 1] if B > 1 else gate, residual=X,
+                           rows_per_batch=rows)
                 else:
-                    N.gemm(Hb, sb["w1"], out=U, epilogue=N.EPI_GELU)
-                    N.gemm(U, sb["w2"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
+                    N.gemm(Hb, sb["w1"], out=U, epilogue=N.EPI_GELU, rows_per_batch=rows)
+                    N.gemm(U, sb["w2"], out=X, epilogue=N.EPI_GATE_RES, gate=gateB[site - 1] if B > 1 else gate, residual=X,
+                           rows_per_batch=rows)
 
         if self.trace is not None:
             self.trace[f"block{(site - 1) // nk}.{(site - 1) % nk}"] = self._traced(X, pending, B)
@@ -468,5 +471,5 @@ class HipDiT:
             allgather_rows_(Y, plan, self.pg)                       # 2.4 MB at cfg 3: every rank gets the full latent
         else:
             N.ln_modulate(X, modfB[0], modfB[1], out=Hb, add_vec=pending, rows_per_batch=rows)
-            N.gemm(Hb, self.w_final, out=Y)
+            N.gemm(Hb, self.w_final, out=Y, rows_per_batch=rows)
         return N.unpatchify(Y, B, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)

@@ -168,7 +168,9 @@ def gemm(a, w, out=None, epilogue=EPI_NONE, gate=None, residual=None, rows_per_b
     t0 = _TIMER.begin("gemm") if _TIMER is not None else None
     lib = load_library()
     rpb = rows_per_batch if rows_per_batch else max(M, 1)
-    splits = lib.drn_gemm_splitk_choice(M, N, K) if (M <= 1024 and splitk is None) else (splitk or 1)
+    # launch decisions that change the summation order come from ONE clip's rows (batch-invariant results)
+    Mb = rpb if (0 < rpb < M and M % rpb == 0) else M
+    splits = lib.drn_gemm_splitk_choice(Mb, N, K) if (Mb <= 1024 and splitk is None) else (splitk or 1)
     if splits > 1:
         # few tokens: the product streams the weights; K is split over several workgroups per tile to keep the CUs busy
         nbytes = lib.drn_gemm_splitk_workspace_bytes(M, N, splits)
@@ -365,7 +367,9 @@ def attention(q, k, v, out=None, heads=None, scale=None, kv_splits=None):
         out = torch.empty((B, Sq, HD), dtype=torch.bfloat16, device=q.device)
     if scale is None:
         scale = 1.0 / (128 ** 0.5)
-    plan = attention_plan(B, H, Sq, Sk) if kv_splits is None else [(0, Sq, int(kv_splits))]
+    # the plan of ONE clip, applied to every clip of the batch: a split of the keys changes the summation order, so it must not
+    # depend on how many clips are stepped together
+    plan = attention_plan(1, H, Sq, Sk) if kv_splits is None else [(0, Sq, int(kv_splits))]
     t0 = _TIMER.begin("attention") if _TIMER is not None else None
     lib = load_library()
     for q0, q1, ns in plan:

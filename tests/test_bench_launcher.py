@@ -1,0 +1,41 @@
+"""bench.py's N > 1 entry as the driver uses it: `python bench.py --gpus N ...` with no torchrun around it.  The launcher must
+start the ranks as a child torch.distributed.run (rendezvous at 127.0.0.1), relay rank 0's ONE JSON line and the exit code.
+Rehearsed on CPU with --dry-run (gloo, no GPU work)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, env=e, timeout=300)
+
+
+def test_gpus2_self_launches_two_ranks():
+    p = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout                    # exactly ONE line on stdout: rank 0's JSON
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["dry_run"] is True
+
+
+def test_single_rank_does_not_spawn():
+    p = _run("--dry-run", "--config", "cfg1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip())
+    assert rec["n_gpus"] == 1 and rec["steps"] == 4      # cfg1's own step count
+
+
+def test_child_failure_is_relayed():
+    # a rank count that contradicts the environment the child sees: the child exits non-zero, so must the launcher (after its
+    # one retry with the all-gather exchange)
+    p = _run("--gpus", "2", "--dry-run", "--blocks", "not-a-number")
+    assert p.returncode != 0 and not p.stdout.strip()
