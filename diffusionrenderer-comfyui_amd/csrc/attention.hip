@@ -38,6 +38,12 @@
 #ifndef ATT_ABL
 #define ATT_ABL 0
 #endif
+// ATT_DIAG 1: diagnostic build (tools/kbench.py attn --diag): every wave sums the shader cycles (s_memtime) it spends in M work /
+// waiting at the end of M (DMA + barrier) / in S work / waiting at the end of S, plus loop cycles and 100 MHz ticks (the clock
+// the chip held), and lane 0 stores the eight sums to the split-KV workspace.  Stamps drain the LDS prefetch: read SHARES only.
+#ifndef ATT_DIAG
+#define ATT_DIAG 0
+#endif
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     f32x16_t s[2];
-    bf16x8_t pb[2][2];
+    bf16x8_t pb[2][2] = {};
 
     // ---- phases, cut into fenced blocks: the fragment reads of one key half (kt2) go into a named block well ahead of the 8
     //      MFMAs that consume it.  A K block and a V block of the same half have disjoint live ranges (32 shared VGPRs).
@@ -252,7 +258,9 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         _Pragma("unroll") for (int kt2 = 0; kt2 < 2; ++kt2) {                                                      \
             float p[16];                                                                                           \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                       \
-                if (ATT_ABL & 1) { p[r] = s[kt2][r]; } else {                                                       \
+                if (ATT_ABL & 1) { p[r] = s[kt2][r]; } else if (ATT_ABL & 64) {                                    \
+                p[r] = s[kt2][r] * scale_log2e - mc; p[r] = p[r] * p[r] + mc;                                      \
+                ps4[r & 3] += p[r]; } else {                                                                       \
                 p[r] = __builtin_amdgcn_exp2f(s[kt2][r] * scale_log2e - mc);                                       \
                 ps4[r & 3] += p[r]; }                                                                              \
             }                                                                                                      \
@@ -345,22 +353,43 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         if ((T) + 3 == nt - 1 && last_rows < KVT) CLAMP_LAST_TILE();    /* before M(t+1) requests the last tile */ \
         FENCE();                                                                              \
         if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);                                          \
+        STAMP(0);                        /* M work */                                         \
         DMA_WAIT(4);                                                                          \
+        STAMP(1);                        /* DMA wait */                                       \
         BARRIER();                                                                            \
+        STAMP(2);                        /* barrier at the end of M */                        \
     } while (0)
     // ---- S(t): softmax only; the first V half of tile t (requested during QK1) is complete at its end
 #define S_SEGMENT()                                                                           \
     do {                                                                                      \
-        SOFTMAX_PHASE();                                                                      \
+        if (!(ATT_ABL & 32)) SOFTMAX_PHASE();                                                 \
         FENCE();                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)"                                                   \
                      : "+v"(va_[0].lo), "+v"(va_[0].hi), "+v"(va_[1].lo), "+v"(va_[1].hi), "+v"(va_[2].lo), "+v"(va_[2].hi), \
                        "+v"(va_[3].lo), "+v"(va_[3].hi), "+v"(va_[4].lo), "+v"(va_[4].hi), "+v"(va_[5].lo), "+v"(va_[5].hi), \
                        "+v"(va_[6].lo), "+v"(va_[6].hi), "+v"(va_[7].lo), "+v"(va_[7].hi) :: "memory"); \
         _Pragma("unroll") for (int f = 0; f < 8; ++f) vc_[f] = JOIN(va_[f]);                  \
+        STAMP(3);                        /* S work */                                         \
         BARRIER();                                                                            \
+        STAMP(4);                        /* barrier at the end of S */                        \
     } while (0)
 
+#if ATT_DIAG
+    unsigned long long dg_[6] = {0, 0, 0, 0, 0, 0}, dg_t = 0, dg_n = 0, dg_r0 = 0;
+#define STAMP(SLOT)                                                                           \
+    do {                                                                                      \
+        FENCE();                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_n) :: "memory");       \
+        FENCE();                                                                              \
+        dg_[SLOT] += dg_n - dg_t;                                                             \
+        dg_t = dg_n;                                                                          \
+    } while (0)
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_r0) :: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t) :: "memory");
+    const unsigned long long dg_c0 = dg_t;
+#else
+#define STAMP(SLOT) do { } while (0)
+#endif
     // tile 0: M(0) = QK(0) only (peeled: the loop body then has ONE fragment history, no merge)
     if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -390,6 +419,18 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);
     DMA_WAIT(0);                                   // (the clamped re-requests of the last tile: nothing may land after the epilogue took the LDS)
     if (grp == 0) BARRIER();                       // balance G1's extra barrier
+#if ATT_DIAG
+    {
+        unsigned long long dg_r1, dg_c1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_r1) :: "memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_c1) :: "memory");
+        if (Opart && nsplit == 1 && lane == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(Opart) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+            dst[0] = dg_[0]; dst[1] = dg_[1]; dst[2] = dg_[2]; dst[3] = dg_[3]; dst[4] = dg_[4];
+            dst[5] = dg_c1 - dg_c0; dst[6] = dg_r1 - dg_r0; dst[7] = (unsigned long long)nt;
+        }
+    }
+#endif
 
     // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l   (or the un-normalised partial when the keys are split)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -48,6 +48,16 @@ class CleanDiffusionRendererPipeline:
             self.model_type = new
             self.config = None
             self.model = None
+            self.__dict__.pop("_h2d_cache", None)     # a new renderer starts from a new clip
+
+    @staticmethod
+    def _resolved(device) -> torch.device:
+        """torch.device("cuda") (what the reference's constructor stores, :81) names the CURRENT device; tensors report an
+        indexed one ("cuda:0").  Compare devices only after resolving the default index."""
+        d = torch.device(device)
+        if d.type == "cuda" and d.index is None:
+            return torch.device("cuda", torch.cuda.current_device())
+        return d
 
     @staticmethod
     def _get_config_hash(config) -> str:
@@ -99,18 +109,21 @@ class CleanDiffusionRendererPipeline:
         reused across calls (the inverse node hands the same clip to 5 consecutive passes)."""
         out = {}
         cache = self.__dict__.setdefault("_h2d_cache", {})
+        dev = self._resolved(self.device)
+        live = {}
         for k, v in data_batch.items():
             if not isinstance(v, torch.Tensor):
                 out[k] = v
                 continue
             key = (id(v), v._version, tuple(v.shape), v.dtype)
-            hit = cache.get(key)
-            if hit is None or hit[0] is not v or hit[1].device != self.device:
-                if len(cache) >= 32:
-                    cache.clear()
-                hit = (v, v.to(device=self.device, dtype=self.dtype))
-                cache[key] = hit
+            hit = live.get(key) or cache.get(key)          # (rgb and video are usually the SAME tensor: one copy)
+            if hit is None or hit[0] is not v or hit[1].device != dev:
+                hit = (v, v.to(device=dev, dtype=self.dtype))
+            live[key] = hit
             out[k] = hit[1]
+        # only the tensors of the batch in hand stay referenced (the node builds a fresh clip tensor per call: an entry of an
+        # earlier call can never hit again and would pin ~0.6 GB of host + HBM per cfg-3 clip)
+        self._h2d_cache = live
         return out
 
     def _load_model_with_config(self):

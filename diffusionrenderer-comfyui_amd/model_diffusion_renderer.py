@@ -161,8 +161,8 @@ class CleanDiffusionRendererModel:
         if hit is not None and hit[0] is x:
             return hit[1]
         latent = self.encode(x, **vae_kwargs).contiguous()
-        if len(self._enc_cache) >= 16:
-            self._enc_cache.clear()
+        while len(self._enc_cache) >= 8:                 # the forward renderer's 8 condition maps of ONE clip; oldest first
+            self._enc_cache.pop(next(iter(self._enc_cache)))
         self._enc_cache[key] = (x, latent)
         return latent
 

@@ -180,3 +180,113 @@ def test_pipeline_error_behaviour(pkg, gpu):
         p.generate_video_passes({"rgb": rgb, "video": rgb, "context_index": idx}, normalize_normal=[False])
     outs = p.generate_video_passes({"rgb": rgb, "video": rgb, "context_index": idx}, normalize_normal=[False, True], seed=1)
     assert len(outs) == 2 and outs[0].shape == (1, 1, 64, 64, 3) and outs[0].dtype.name == "uint8"
+
+
+class _CountingVAE(StubVAE):
+    def __init__(self):
+        self.encodes = 0
+
+    def encode(self, x):
+        self.encodes += 1
+        return super().encode(x)
+
+
+def test_clip_is_uploaded_and_encoded_once_across_passes(pkg, gpu):
+    """The pipeline as the loader node builds it (device = torch.device("cuda"), NOT overridden): the inverse node hands the
+    same clip tensor to five generate_video calls; the host->device copy and the tokenizer encode must happen once (N1)."""
+    net = tiny_net(pkg, 256, 1, 2)
+    sw = pkg.synthetic_weights
+    cfg = pkg.diffusion_renderer_config.get_inverse_renderer_config()
+    cfg["net"] = dict(net)
+    model = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(cfg, device=gpu)
+    model.load_state_dict(sw.synth_state_dict(net, BF, device=gpu), strict=True)
+    vae = _CountingVAE()
+    p = pkg.diffusion_renderer_pipeline.CleanDiffusionRendererPipeline(
+        "/nonexistent", "x.pt", model_type=None, vae_instance=vae, model_instance=model, guidance=0.0, num_steps=1)
+    assert p.device == torch.device("cuda")                     # the reference's constructor value (:81), no index
+    p.set_model_type("inverse")
+    rgb = sw.synth_tensor("cache.rgb", (1, 3, 1, 64, 64), torch.float32)
+    outs = []
+    for ci in (0, 3, 4):
+        outs.append(p.generate_video({"rgb": rgb, "video": rgb, "context_index": torch.full((1, 1), ci, dtype=torch.long)}, seed=1))
+    assert vae.encodes == 1
+    assert len(p._h2d_cache) <= 3 and len(model._enc_cache) == 1
+    # a new clip replaces the cached one (nothing accumulates)
+    rgb2 = rgb.clone()
+    p.generate_video({"rgb": rgb2, "video": rgb2, "context_index": torch.zeros((1, 1), dtype=torch.long)}, seed=1)
+    assert vae.encodes == 2 and len(p._h2d_cache) <= 3 and len(model._enc_cache) <= 2
+    # in-place edits of the clip are seen (version counter)
+    rgb2.mul_(0.5)
+    p.generate_video({"rgb": rgb2, "video": rgb2, "context_index": torch.zeros((1, 1), dtype=torch.long)}, seed=1)
+    assert vae.encodes == 3
+
+
+def test_loader_node_load_pipeline_and_one_pass(pkg, gpu, tmp_path, monkeypatch):
+    """LoadDiffusionRendererModel.load_pipeline as ComfyUI calls it (reference nodes.py:74-127): VAE directory (config.json +
+    safetensors) under <models>/vae/Cosmos-1.0-Tokenizer-CV8x8x8/vae, checkpoint {"model": state_dict} through
+    comfy.utils.load_torch_file, strict load_state_dict, pipeline(guidance 0, 15 steps, seed 42) - then one inverse pass.
+    ComfyUI's modules are faked; the network is shrunk (same code path, tiny weights)."""
+    import json
+    import sys
+    import types
+    from safetensors.torch import save_file
+
+    sw = pkg.synthetic_weights
+    models = tmp_path / "models"
+    vae_dir = models / "vae" / "Cosmos-1.0-Tokenizer-CV8x8x8" / "vae"
+    vae_dir.mkdir(parents=True)
+    (vae_dir / "config.json").write_text(json.dumps({**{k: (list(v) if isinstance(v, tuple) else v) for k, v in sw.COSMOS_CV8x8x8.items()},
+                                                     "_class_name": "AutoencoderKLCosmos"}))
+    save_file({k: v.contiguous() for k, v in sw.synth_vae_state_dict().items()}, str(vae_dir / "diffusion_pytorch_model.safetensors"))
+    net = tiny_net(pkg, 256, 1, 2)
+    sd = sw.synth_state_dict(net, BF)
+    assert any(k.startswith("logvar.") for k in sd) and any(k.startswith("net.") for k in sd)     # the checkpoint contract (a23)
+    ckpt_dir = models / "diffusion_models"
+    ckpt_dir.mkdir()
+    torch.save({"model": sd}, str(ckpt_dir / "tiny.pt"))
+
+    fp = types.ModuleType("folder_paths")
+    fp.models_dir = str(models)
+    fp.get_filename_list = lambda kind: ["tiny.pt"] if kind == "diffusion_models" else []
+    fp.get_full_path = lambda kind, name: str(models / kind / name)
+    comfy = types.ModuleType("comfy")
+    mm = types.ModuleType("comfy.model_management")
+    mm.get_torch_device = lambda: gpu
+    mm.soft_empty_cache = lambda: None
+    cu = types.ModuleType("comfy.utils")
+    loads = []
+
+    def load_torch_file(path, safe_load=False):
+        loads.append((path, safe_load))
+        return torch.load(path, map_location="cpu", weights_only=True)
+    cu.load_torch_file = load_torch_file
+    comfy.model_management, comfy.utils = mm, cu
+    for name, mod in (("folder_paths", fp), ("comfy", comfy), ("comfy.model_management", mm), ("comfy.utils", cu)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    tiny_cfg = dict(pkg.diffusion_renderer_config.get_inverse_renderer_config(), net=dict(net))
+    monkeypatch.setattr(pkg.nodes, "get_inverse_renderer_config", lambda *a, **k: dict(tiny_cfg))
+
+    Loader = pkg.NODE_CLASS_MAPPINGS["LoadDiffusionRendererModel"]
+    assert Loader.INPUT_TYPES()["required"]["model"][0] == ["tiny.pt"]
+    (pipe,) = Loader().load_pipeline("tiny.pt")
+    assert loads == [(str(ckpt_dir / "tiny.pt"), True)]
+    assert (pipe.guidance, pipe.num_steps, pipe.seed, pipe.model_type) == (0.0, 15, 42, None)
+    assert pipe.vae_instance.latent_ch == 16 and pipe.vae_instance.spatial_compression_factor == 8
+    pipe.num_steps = 2
+    image = sw.synth_tensor("ldr.img", (1, 9, 64, 64, 3), torch.float32).abs()
+    outs = pkg.NODE_CLASS_MAPPINGS["Cosmos1InverseRenderer"]().run_inverse_pass(pipe, image, guidance=0.0, seed=42)
+    assert len(outs) == 5 and all(o.shape == (9, 64, 64, 3) and 0.0 <= o.min() and o.max() <= 1.0 for o in outs)
+    # a missing tokenizer directory / a checkpoint with a wrong tensor fail like the reference (FileNotFoundError / strict load)
+    (vae_dir / "config.json").rename(vae_dir / "config.json.bak")
+    with pytest.raises(ValueError, match="Failed to load VAE"):
+        Loader().load_pipeline("tiny.pt")
+    (vae_dir / "config.json.bak").rename(vae_dir / "config.json")
+    bad = dict(sd)
+    bad.pop("net.final_layer.linear.weight")
+    torch.save({"model": bad}, str(ckpt_dir / "bad.pt"))
+    with pytest.raises(RuntimeError, match="state_dict"):
+        Loader().load_pipeline("bad.pt")
+    import shutil
+    shutil.rmtree(models / "vae")
+    with pytest.raises(FileNotFoundError):
+        Loader().load_pipeline("tiny.pt")

@@ -89,3 +89,21 @@ def test_bf16_mode_tracks_fp32(pkg):
         z32 = _oracle(pkg).encode(x)
         z16 = _oracle(pkg, torch.bfloat16).encode(x)
     assert ((z16.float() - z32).norm() / z32.norm()).item() < 5e-2
+
+
+def test_tokenizer_hyperparameters_equal_reference_config(pkg):
+    """synthetic_weights.COSMOS_CV8x8x8 (what HipCosmosTokenizer and the oracle are built from) against the hyper-parameters of
+    the reference's VAE_config.json:1-30, committed as tests/golden/vae_config_hparams.json by tools/make_goldens.py."""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "vae_config_hparams.json")) as f:
+        ref = json.load(f)
+    ours = pkg.synthetic_weights.COSMOS_CV8x8x8
+    for k, v in ours.items():
+        assert k in ref, k
+        assert (list(v) if isinstance(v, tuple) else v) == ref[k], (k, v, ref[k])
+    assert ref["_class_name"] == "AutoencoderKLCosmos" and ref["latents_mean_count"] == 16 * 16     # unused by the reference (F10)
+    # every structural key of the reference config is covered
+    assert set(ref) - set(ours) == {"_class_name", "_diffusers_version", "latents_mean_count", "latents_mean_sum",
+                                    "latents_std_count", "latents_std_sum"}

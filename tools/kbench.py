@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--splits", type=int, default=1, help="attention: split-KV chunks (drn_attention_splitkv_bf16)")
     ap.add_argument("--tiles", default="-1", help="gemm: comma list of forced tile kernels (-1 auto, 0 128^2, 1 256^2, 2 144x256)")
     ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
+    ap.add_argument("--diag", default="", help="attention: library built with -DATT_DIAG=1; prints the per-segment cycle shares")
     args = ap.parse_args()
     pkg = load_package()
     N = pkg.native
@@ -84,6 +85,29 @@ def main():
                 lib.drn_gemm_force_tile(-1)
                 assert rc == 0, rc
               cases.append((f"gemm {nm} [{S}x{K}]x[{Nn}x{K}] tile {tile}", run_gemm, 2.0 * S * Nn * K))
+    if args.diag and "attn" in args.what:
+        lib = ctypes.CDLL(os.path.abspath(args.diag))
+        for name, at in N.SIGNATURES.items():
+            if hasattr(lib, name):
+                getattr(lib, name).argtypes = at
+        Sk = args.Sk or S
+        nwg = ((S + 255) // 256) * H
+        dbg = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+        for _ in range(40):                        # ~0.2 s of back-to-back launches: the clock settles under load
+            rc = lib.drn_attention_splitkv_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(), 1, H, S, Sk,
+                                                3 * D, 3 * D, 3 * D, D, 0, 0, 0, 0, 128 ** -0.5, 1, dbg.data_ptr(), st)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        d = dbg.view(nwg, 8, 8).double().cpu()
+        names = ["M work", "DMA wait", "barrier after M", "S work", "barrier after S"]
+        for g, gname in ((slice(0, 4), "G0 (waves 0-3)"), (slice(4, 8), "G1 (waves 4-7)")):
+            x = d[:, g, :].reshape(-1, 8)
+            tiles = x[:, 7].median().item()
+            tot = x[:, 5].median().item()
+            print(f"{gname}: loop {tot:.0f} cycles = {tot / tiles:.0f} per tile over {tiles:.0f} tiles; in-kernel clock "
+                  f"{(x[:, 5] / x[:, 6]).median().item() * 100:.0f} MHz")
+            for i, nm in enumerate(names):
+                print(f"    {nm:18s} {x[:, i].median().item() / tiles:8.0f} cycles per tile  ({x[:, i].median().item() / tot * 100:5.1f} %)")
     for name, fn, fl in cases:
         times = [[] for _ in handles]
         for lib in handles:

@@ -425,6 +425,22 @@ def full_width_cases(ref):
     return files
 
 
+def vae_config_case():
+    """Hyper-parameters of the reference's VAE_config.json (the only in-repo specification of the tokenizer; read by no
+    reference code) as a small JSON fixture; the 2 x 256 latent mean / std values as count + sums."""
+    import json
+    with open("/root/reference/VAE_config.json") as f:
+        c = json.load(f)
+    out = {k: v for k, v in c.items() if k not in ("latents_mean", "latents_std")}
+    for k in ("latents_mean", "latents_std"):
+        out[k + "_count"] = len(c[k])
+        out[k + "_sum"] = float(sum(c[k]))
+    path = os.path.join(GOLD, "vae_config_hparams.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path)
+
+
 def save(name, tensors, meta):
     os.makedirs(GOLD, exist_ok=True)
     path = os.path.join(GOLD, name)
@@ -465,6 +481,8 @@ def main():
         t, m = dit_case(ref, "wide1", 4096, 1, 32, (1, 32, 32), 2.0, 3, dtypes=(torch.bfloat16,))
         save("dit_wide1.safetensors", t, m)
         print(f"wide1 took {time.time()-t0:.1f}s")
+    if want("vaecfg"):
+        vae_config_case()
     if want("cond"):
         save("conditions.safetensors", *conditions_case(ref))
     if args.full and want("fullwidth"):
