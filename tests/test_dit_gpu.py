@@ -139,6 +139,36 @@ def test_full_size_block_cfg3_matches_oracle(pkg, gpu):
     assert d <= max(2.0 * e_ref, 2e-3), (d, e_ref)
 
 
+def test_full_size_forward_variant_block_cfg5_matches_oracle(pkg, gpu):
+    """BASELINE config 5 shapes: the FORWARD renderer's network (in_channels 16 + 136 condition channels + mask = 153 -> patch
+    embed K = 612, no context embedding: the cross-attention adds exactly to_out(to_v(0)) = 0) at the full clip (latent
+    8 x 72 x 128 -> S = 18 432 tokens, D = 4096, 32 heads), ONE transformer block, against the CPU oracle on the same seeded
+    inputs.  The reference cannot run this pass as committed; the oracle evaluates its network code by the intent
+    of get_forward_renderer_config, pinned at small size by dit_tinyF_forward.safetensors."""
+    import time
+    from oracle import dit_oracle as O
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    net = tiny_net(pkg, 4096, 1, 32, forward=True)
+    assert net["additional_concat_ch"] == 136 and not net["use_context_embedding"]
+    sw = pkg.synthetic_weights
+    sd = sw.synth_state_dict(net, torch.bfloat16)
+    F_, h, w = 8, 72, 128
+    x = sw.synth_tensor("fwd.x", (1, 16, F_, h, w), torch.float32, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor("fwd.c", (1, 136, F_, h, w), torch.float32, scale=1.0).to(torch.bfloat16)
+    cond[:, 16::17] = 1.0                                      # the mask channels of the 8 encoded maps (ones: map present)
+    t, ci = torch.tensor(7.0), torch.zeros((1, 1), dtype=torch.long)
+    dit = pkg.dit_engine.HipDiT(net, {k: v.to(gpu) for k, v in sd.items()}, device=gpu)
+    y = dit(x.to(gpu), t, cond.to(gpu), ci).cpu()
+    t0 = time.time()
+    with torch.no_grad():
+        ref16 = O.DitOracle(sd, net, dtype=torch.bfloat16).forward(x, t, cond, ci)
+        exact = O.DitOracle(sd, net, dtype=torch.float32, tables_dtype=torch.bfloat16).forward(x, t, cond, ci)
+    e_ref, e_hip, d = rel_l2(ref16, exact), rel_l2(y, exact), rel_l2(y, ref16)
+    print(f"cfg5 forward-variant block: e_ref={e_ref:.3e} e_hip={e_hip:.3e} hip-vs-ref16={d:.3e} (oracle {time.time() - t0:.0f}s)")
+    assert e_hip <= max(1.5 * e_ref, 1e-3), (e_hip, e_ref)
+    assert d <= max(2.0 * e_ref, 2e-3), (d, e_ref)
+
+
 def test_full_model_cfg3_batch_and_determinism(pkg, gpu, full28_dit):
     """The whole 28-block, 7.2 B-parameter model at BASELINE config 3 (S = 18 432 tokens per clip).  No CPU oracle finishes
     this size in test time, so size-independent properties stand in: the forward is deterministic (same bits twice), two
