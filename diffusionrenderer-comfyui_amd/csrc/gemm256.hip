@@ -21,6 +21,11 @@
 #include <stdlib.h>
 #include "drn_common.h"
 
+// G256_ABL: timing-only ablation builds (results are WRONG; shipped with 0): 1 = no DMA in the K loop (stale LDS), 2 = no fragment
+// reads, 4 = no MFMAs, 8 = no epilogue math / stores (accumulators kept alive)
+#ifndef G256_ABL
+#define G256_ABL 0
+#endif
 #define TB 256
 #define BK 64
 #define HALF_BYTES (128 * BK * 2)          // 16 KiB
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     const int64_t c_tile_off = (n0 >> cbc) * cbs + (n0 & ((1ll << cbc) - 1)) - n0;
 #define DMA(H, KT)                                                                                                     \
     do {                                                                                                               \
+        if ((G256_ABL & 1) && (KT) > 1) break;                                                                         \
         char* dst_ = smem + ((KT) & 1) * STAGE_BYTES + (H) * HALF_BYTES + dma_off;                                     \
         const int64_t ko_ = (H) < 2 ? A_KOFF(KT) : (int64_t)(KT) * BK;                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][0] + ko_), (lptr_t)dst_, 16, 0, 0);                          \
@@ -120,10 +126,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[i][mt][j][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8_t af[4][2], wf0[2][2], wf1[2][2];   // [mt][ks], W0 / W1 fragments [nt][ks] (W0 lives through phases 1..4)
+    bf16x8_t af[4][2] = {}, wf0[2][2] = {}, wf1[2][2] = {};   // [mt][ks], W0 / W1 fragments [nt][ks] (W0 lives through phases 1..4)
 
 #define READ_A(STAGE, I)                                                                                \
     do {                                                                                                \
+        if (G256_ABL & 2) break;                                                                        \
         const char* b_ = smem + (STAGE) * STAGE_BYTES + (I) * HALF_BYTES;                               \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                              \
             af[mt][0] = *reinterpret_cast<const bf16x8_t*>(b_ + offa + mt * 2048);                      \
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     } while (0)
 #define READ_W(STAGE, J, WF)                                                                            \
     do {                                                                                                \
+        if (G256_ABL & 2) break;                                                                        \
         const char* b_ = smem + (STAGE) * STAGE_BYTES + (2 + (J)) * HALF_BYTES;                         \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                              \
             WF[nt][0] = *reinterpret_cast<const bf16x8_t*>(b_ + offw + nt * 2048);                      \
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                            \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
+                    if (G256_ABL & 4) { asm volatile("" :: "v"(WF[nt][ks]), "v"(af[mt][ks])); } else                        \
                     acc[I][mt][J][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nt][ks], af[mt][ks], acc[I][mt][J][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                  \
     } while (0)
@@ -213,6 +222,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     //      fq 0: n 0..7, fq 1: n 16..23, fq 2: n 8..15, fq 3: n 24..31  ->  16 x 16-B stores, 64 B contiguous per row.
     //      Partners share fr, i.e. the same output row, so row validity is identical on both sides of a swap; every lane
     //      executes the swaps (rows past M compute on a clamped row and are not stored).
+    if (G256_ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(acc[i][mt][j][nt]));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

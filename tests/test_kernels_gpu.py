@@ -368,6 +368,33 @@ def test_gemm256_kernel(pkg, gpu, M, N, K, epi, tile=1):
     assert ok, msg
 
 
+# ------------------------------------------------------------------------------------------------ streamed 256x256 GEMM (tile kernel 3)
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 256, 64, 0), (1100, 512, 128, 0), (2304, 768, 192, 1), (1537, 256, 320, 2),
+                                       (4096, 1024, 1024, 2), (300, 256, 4096, 1), (18432, 512, 448, 0)])
+def test_gemm256_streamed_kernel(pkg, gpu, M, N, K, epi):
+    """Same problems through the streamed schedule (1, 2, 3, 5, 7, 16, 64 K steps: prologue-only, odd and even step counts)."""
+    test_gemm256_kernel(pkg, gpu, M, N, K, epi, tile=3)
+
+
+def test_gemm256_streamed_identity_and_equals_first_generation(pkg, gpu):
+    lib = pkg.native.load_library()
+    M = K = 1024
+    N = 512
+    a = torch.eye(M, K, dtype=BF, device=gpu)
+    w = (torch.arange(N * K, device=gpu).reshape(N, K) % 251).to(BF)
+    a2, w2 = rnd((2000, 1024), gpu, seed=120), rnd((768, 1024), gpu, 1 / 32, seed=121)
+    outs = {}
+    for tile in (1, 3):
+        lib.drn_gemm_force_tile(tile)
+        try:
+            outs[tile] = (pkg.native.gemm(a, w), pkg.native.gemm(a2, w2))
+        finally:
+            lib.drn_gemm_force_tile(-1)
+    assert torch.equal(outs[3][0], w.t().contiguous())
+    # same tile, same K order inside an MFMA chain: the two schedules accumulate identically
+    assert torch.equal(outs[1][1], outs[3][1])
+
+
 # ------------------------------------------------------------------------------------------------ 144x256 GEMM (token bands, M = 2304 k)
 @pytest.mark.parametrize("M,N,K,epi", [(144, 256, 64, 0), (2304, 256, 128, 0), (1000, 512, 192, 0), (2304, 768, 256, 1),
                                        (1537, 256, 320, 2), (2304, 4096, 1024, 2), (150, 256, 4096, 0)])
@@ -375,7 +402,7 @@ def test_gemm144_kernel(pkg, gpu, M, N, K, epi):
     test_gemm256_kernel(pkg, gpu, M, N, K, epi, tile=2)
 
 
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 def test_gemm_blocked_layouts(pkg, gpu, tile):
     """drn_gemm_bf16_blocked: C written as planes of columns / A read from planes of columns == the plain product regrouped
     (the rank-major slabs either side of the sequence-parallel all-to-all)."""
