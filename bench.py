@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
+TRAFFIC_PROFILE = "r02_pmc_traffic.json"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 
@@ -253,14 +254,20 @@ def main():
     # (sharded runs: every 29th launch, the event pairs sit on rank 0 only and would skew its step against the other ranks)
     timer = N.KernelTimer(sample_every=7 if world == 1 else 29) if (rank == 0 and S > 4096 and not os.environ.get("DRN_NO_TIMER")) else None
     N.set_timer(timer)
+    xtimer = pkg.parallel.ExchangeTimer() if (pg is not None and rank == 0) else None      # (also the 1-rank RCCL rehearsal)
+    pkg.parallel.set_exchange_timer(xtimer)
+    host_enqueue = 0.0
     t0 = time.perf_counter()
     # inside the timed region: the timed steps' AdaLN vectors, batched as generate_samples_from_batch does before its loop
     model.net.prepare_timesteps([float(model.scheduler.timesteps[i]) for i in range(args.warmup, total)])
     for i in range(args.warmup, total):
+        h0 = time.perf_counter()
         xt = one_step(i, xt)
+        host_enqueue += time.perf_counter() - h0      # launches are asynchronous: this is the host's share of a step
     barrier()
     elapsed = time.perf_counter() - t0
     N.set_timer(None)
+    pkg.parallel.set_exchange_timer(None)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -335,14 +342,16 @@ def main():
         try:
             if S != 18432 or args.blocks != 28 or world != 1:
                 raise KeyError("profile was taken on the headline configuration only")
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)) as f:
                 traffic = json.load(f)["families"][dom]["bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "mfma", "kernel": {"gemm": "gemm256_kernel" if world == 1 else "gemm144_kernel", "attention": "attention_fwd_kernel"}[dom],
+        roofline = {"bound": "mfma", "kernel": {"gemm": "gemm256s_kernel" if world == 1 else "gemm144_kernel", "attention": "attention_fwd_kernel"}[dom],
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes/launch (L2-miss traffic incl. Infinity-Cache hits; profiles/r01_pmc_traffic.json)",
+                    "traffic_unit": "bytes/launch (L2-miss traffic incl. Infinity-Cache hits)",
+                    "traffic_source": f"profiles/{TRAFFIC_PROFILE}: committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command, NOT "
+                                      "measured in this run (goes stale when a kernel changes)",
                     "launches_per_step": d.get("launches_seen", d["launches"]) // args.steps, "launches_timed": d["launches"],
                     "avg_launch_ms": round(d["ms_avg"], 4),
                     "per_kernel": {k: {"tflops": round(v["flops"] / (v["ms_total"] * 1e-3) / 1e12, 1),
@@ -360,7 +369,8 @@ def main():
         out = {
             "metric": "denoising_steps_per_sec", "value": round(steps_s, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "rccl_ranks": world,
+            "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 2),
             "config": {"workload": f"inverse pass, {args.frames}f x {args.height} x {args.width} clip: EDM Euler step = 1 DiT "
                                    f"forward (D=4096, {args.blocks} blocks, 32 heads) over S={S} tokens, guidance 0",
                        "latent": [16, F_, h, w], "tokens": S, "parallelism": (f"sp{world} (token bands; self-attention exchange: "
@@ -372,6 +382,12 @@ def main():
             "frames_per_sec_35step_pass_dit_only": round(args.frames / (35 * ms * 1e-3), 3),
             "roofline": roofline,
         }
+        if xtimer is not None:
+            # rank 0's view: time its compute stream waited in front of each exchange, per self-attention layer
+            xs = xtimer.summary()
+            layers = max(1, args.blocks * args.steps)
+            out["exchange"] = {"kind": model.net.exchange, "exposed_ms_per_layer": {k: round(v["ms_total"] / layers, 4) for k, v in xs.items()},
+                               "exposed_ms_per_step": round(sum(v["ms_total"] for v in xs.values()) / args.steps, 3)}
         if cfg_ms is not None:
             out["guidance_2"] = {"steps_per_sec": round(1e3 / cfg_ms, 4), "ms_per_step": round(cfg_ms, 2),
                                  "note": "cond + uncond forwards of one Euler step as one batch of two clips (pipeline default guidance)"}

@@ -27,7 +27,7 @@ import torch
 
 from . import native as N
 from .host_tables import rope_cos_sin, timestep_sinusoid
-from .parallel import ShardPlan, allgather_rows_, alltoall_rows_, group_info
+from .parallel import ShardPlan, allgather_rows_, alltoall_rows_, group_info, wait_exchange
 
 
 def _pad_cols(w: torch.Tensor, mult: int) -> torch.Tensor:
@@ -419,17 +419,14 @@ class HipDiT:
                             N.gemm(Hb, sb["wqkv"][:D], out=ws["qb"])
                             N.permute_021(ws["qb"].view(rows, world, W), out=ws["sq"])
                         work_q = alltoall_rows_(ws["sq"], rq.view(world, rows, W), self.pg, async_op=True)
-                        if work_kv is not None:
-                            work_kv.wait()
+                        wait_exchange(work_kv, "a2a k|v")
                         k, v = rkv[:, :W], rkv[:, W:]
                         N.qk_norm_rope(None, k, None, sb["kn"], cos, sin, hpr, tokens_per_batch=S)
-                        if work_q is not None:
-                            work_q.wait()
+                        wait_exchange(work_q, "a2a q")
                         N.qk_norm_rope(rq, None, sb["qn"], None, cos, sin, hpr, tokens_per_batch=S)
                         N.attention(rq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
                         work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
-                        if work is not None:
-                            work.wait()
+                        wait_exchange(work, "a2a o (return)")
                         if fused:
                             N.gemm_blocked(oback, sb["wo"], X, rows, epilogue=N.EPI_GATE_RES, gate=gate, residual=X, a_planes=True)
                             continue
@@ -446,8 +443,7 @@ class HipDiT:
                         N.gemm(Hb, sb["wqkv"][:D], out=q)
                         N.qk_norm_rope(q, None, sb["qn"], None, cos, sin, self.heads,
                                        tokens_per_batch=rows, pos_offset=plan.start)
-                        if work is not None:
-                            work.wait()
+                        wait_exchange(work, "gather k|v")
                         k, v = KV[:, :D], KV[:, D:]
                     if self.exchange == "a2a":
                         pass

@@ -49,6 +49,45 @@ def group_info(group=None) -> Tuple[int, int]:
 SINGLE_RANK_COLLECTIVES = False
 
 
+class ExchangeTimer:
+    """How long the compute stream sits in front of an exchange (bench.py, N > 1): an event pair around every wait() of an
+    asynchronous collective.  work.wait() makes the CURRENT stream wait for RCCL's stream, so the time between the two events is
+    the part of the exchange that compute did not cover ("exposed"); an exchange that has already finished costs ~0."""
+
+    def __init__(self):
+        self.records = []          # (tag, start_event, end_event)
+
+    def summary(self):
+        out = {}
+        for tag, a, b in self.records:
+            d = out.setdefault(tag, {"waits": 0, "ms_total": 0.0})
+            d["waits"] += 1
+            d["ms_total"] += a.elapsed_time(b)
+        return out
+
+
+_XTIMER = None
+
+
+def set_exchange_timer(t):
+    global _XTIMER
+    _XTIMER = t
+
+
+def wait_exchange(work, tag: str):
+    """work.wait() (None = nothing was issued), timed when an ExchangeTimer is installed."""
+    if work is None:
+        return
+    if _XTIMER is None or not torch.cuda.is_available():
+        work.wait()
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    work.wait()
+    b.record()
+    _XTIMER.records.append((tag, a, b))
+
+
 def allgather_rows_(full: torch.Tensor, plan: ShardPlan, group=None, async_op: bool = False):
     """In-place all-gather: `full` is [S, C] contiguous, this rank's band already holds its rows."""
     if plan.world == 1 and not (SINGLE_RANK_COLLECTIVES and group is not None):

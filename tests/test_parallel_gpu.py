@@ -224,3 +224,27 @@ def test_tokenizer_row_bands_equal_single_rank(gpu):
         assert shz == (1, 16, 2, 8, 12) and shv == (1, 3, 9, 64, 96)
         assert alone_ok
         assert ez == 0.0 and ev == 0.0 and same_z == 1.0 and same_v == 1.0
+
+
+@pytest.mark.parametrize("exchange", ["a2a", "gather"])
+def test_bench_under_torchrun_one_rank_rccl(gpu, exchange):
+    """bench.py as a rank of torch.distributed.run (1 rank on this box's one GPU, RCCL backend): process-group start-up, the
+    exchange probe, both sequence-parallel exchanges through real RCCL calls, the exchange-exposure timers and the N > 1 fields
+    of the JSON line.  2 of the 28 blocks; the transport over xGMI itself needs the driver's 8-GPU node."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DRN_SP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "2", "--steps", "1",
+           "--warmup", "1", "--no-cpu-baseline", "--no-tokenizer", "--no-cfg"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["rccl_ranks"] == 1 and rec["value"] > 0 and rec["host_enqueue_ms_per_step"] > 0
+    ex = rec["exchange"]
+    want = {"a2a": {"a2a k|v", "a2a q", "a2a o (return)"}, "gather": {"gather k|v"}}[exchange]
+    assert ex["kind"] == exchange and set(ex["exposed_ms_per_layer"]) == want, ex
+    print(exchange, ex)
