@@ -13,7 +13,13 @@
  *     enqueued, never synchronised;
  *   - return value: DRN_OK (0), DRN_EINVAL (-1) for a shape/alignment the kernels do not
  *     support (nothing was launched), or a positive hipError_t from the launch;
- *   - not thread-safe per stream; one host thread per process/GPU (ComfyUI runs nodes serially).
+ *   - not thread-safe per stream; one host thread per process/GPU (ComfyUI runs nodes serially);
+ *   - multi-GPU: one process per GPU.  SURVEY.md 8(b) sketched a `drn_comm_init(ncclUniqueId, rank, world)` entry; it was
+ *     NOT built: the library has no communication state at all.  The sequence-parallel exchanges (head <-> token all-to-all,
+ *     K|V all-gather; parallel.py) are issued by the host through torch.distributed (backend "nccl" = RCCL over xGMI) on the
+ *     tensors the kernels below read and write - drn_gemm_bf16_blocked / drn_permute_021 produce and consume the rank-major
+ *     slabs of those exchanges directly.
+ *   - drn_attention_bf16: the output base and its row / batch strides must allow 16-byte stores (o % 16 == 0, ldo % 8 == 0).
  */
 #ifndef DRN_H
 #define DRN_H

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--splits", type=int, default=1, help="attention: split-KV chunks (drn_attention_splitkv_bf16)")
     ap.add_argument("--tiles", default="-1", help="gemm: comma list of forced tile kernels (-1 auto, 0 128^2, 1 256^2, 2 144x256)")
     ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
+    ap.add_argument("--cold", type=int, default=1, help="gemm: rotate over this many copies of the weights (and activations) so that "
+                    "they come from HBM, not from the 256 MB Infinity Cache, as inside the model (4-6 copies)")
     ap.add_argument("--diag", default="", help="attention: library built with -DATT_DIAG=1; prints the per-segment cycle shares")
     args = ap.parse_args()
     pkg = load_package()
@@ -71,13 +73,18 @@ def main():
         for (Nn, K, epi, nm) in [(3 * D, D, 0, "qkv"), (D, D, 2, "out+gate"), (4 * D, D, 1, "mlp1+gelu"), (D, 4 * D, 2, "mlp2+gate")]:
             A = a if K == D else rnd(S, K, scale=0.3)
             Wt = rnd(Nn, K, scale=K ** -0.5)
+            As = [A] + [A.clone() for _ in range(args.cold - 1)]
+            Ws = [Wt] + [Wt.clone() for _ in range(args.cold - 1)]
             C = torch.empty(S, Nn, dtype=torch.bfloat16, device=dev)
             R = rnd(S, Nn) if epi == 2 else None
             gate = rnd(1, Nn) if epi == 2 else None
+            turn = [0]
 
             tiles = [int(t) for t in args.tiles.split(",")]
             for tile in tiles:
-              def run_gemm(lib, A=A, Wt=Wt, C=C, R=R, gate=gate, Nn=Nn, K=K, epi=epi, tile=tile):
+              def run_gemm(lib, As=As, Ws=Ws, C=C, R=R, gate=gate, Nn=Nn, K=K, epi=epi, tile=tile, turn=turn):
+                turn[0] = (turn[0] + 1) % len(As)
+                A, Wt = As[turn[0]], Ws[turn[0]]
                 lib.drn_gemm_force_tile(tile)
                 rc = lib.drn_gemm_bf16(A.data_ptr(), Wt.data_ptr(), C.data_ptr(), S, Nn, K, K, K, Nn, epi,
                                        gate.data_ptr() if gate is not None else None,
