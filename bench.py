@@ -385,9 +385,9 @@ def main():
         if xtimer is not None:
             # rank 0's view: time its compute stream waited in front of each exchange, per self-attention layer
             xs = xtimer.summary()
-            layers = max(1, args.blocks * args.steps)
-            out["exchange"] = {"kind": model.net.exchange, "exposed_ms_per_layer": {k: round(v["ms_total"] / layers, 4) for k, v in xs.items()},
-                               "exposed_ms_per_step": round(sum(v["ms_total"] for v in xs.values()) / args.steps, 3)}
+            out["exchange"] = {"kind": model.net.exchange, "exposed_ms_per_layer": {k: round(v["ms_avg"], 4) for k, v in xs.items()},
+                               "exposed_ms_per_step": round(sum(v["ms_avg"] * v["waits"] for v in xs.values()) / args.steps, 3),
+                               "waits_timed": {k: f'{v["timed"]} of {v["waits"]}' for k, v in xs.items()}}
         if cfg_ms is not None:
             out["guidance_2"] = {"steps_per_sec": round(1e3 / cfg_ms, 4), "ms_per_step": round(cfg_ms, 2),
                                  "note": "cond + uncond forwards of one Euler step as one batch of two clips (pipeline default guidance)"}

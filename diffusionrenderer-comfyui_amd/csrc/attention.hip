@@ -44,6 +44,11 @@
 #ifndef ATT_DIAG
 #define ATT_DIAG 0
 #endif
+// ATT_DMA_IN_S: how many of a wave's 4 DMA pieces per tile are requested in the softmax segment instead of the MFMA segment
+// (0..4; a piece costs its wave ~60-80 cycles of issue)
+#ifndef ATT_DMA_IN_S
+#define ATT_DMA_IN_S 0
+#endif
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     bf16x8_t vc_[8];                               // first half of V[t], joined, carried from the end of S(t) into M(t+1)
     int kbuf = 0, vbuf = 0;                        // t % NKB, t % NVB
     int kreq = 2 % NKB, vreq = 2 % NVB;            // buffers of the tile that M(t) requests (t + 2)
+    int kreq_s = kreq, vreq_s = vreq;              // the same for the pieces requested in S(t)
 
     // ---- M(t) = PV(t-1) . QK(t): four blocks of 8 MFMAs.  Every MFMA is followed, in its own issue shadow, by the fragment
     //      read(s) that the MFMA one block later needs (a full block = 256 cycles of latency budget), and is preceded by the
@@ -329,10 +335,17 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         FENCE();                                                                              \
     } while (0)
 #define ZERO_S(KT2) do { _Pragma("unroll") for (int r = 0; r < 16; ++r) s[KT2][r] = 0.f; } while (0)
-#define REQ_PIECE(P, T)                                                                       \
+#define REQ_PIECE_NOW(P, T)                                                                   \
     do {                                                                                      \
         if (!(ATT_ABL & 16)) DMA_PIECE(P, min((T) + 2, nt - 1), kreq, vreq);                  \
         FENCE();                                                                              \
+    } while (0)
+    // pieces 0 .. ATT_DMA_IN_S-1 wait for the softmax segment (S_REQ), the others are requested between the MFMA blocks
+#define REQ_PIECE(P, T) do { if ((P) >= ATT_DMA_IN_S) REQ_PIECE_NOW(P, T); } while (0)
+#define S_REQ(T)                                                                              \
+    do {                                                                                      \
+        _Pragma("unroll") for (int p_ = 0; p_ < ATT_DMA_IN_S; ++p_)                           \
+            if (!(ATT_ABL & 16)) DMA_PIECE(p_, min((T) + 2, nt - 1), kreq_s, vreq_s);         \
     } while (0)
     // QK(t) blocks + end of M(t): the DMA of tile t+1 (requested in M(t-1), older than this segment's 4 pieces) has landed
 #define M_QK(T)                                                                               \
@@ -348,20 +361,22 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         REQ_PIECE(3, T);                                                                      \
         STEP_QK1(4); STEP_QK1(5); STEP_QK1(6); STEP_QK1(7);                                   \
         QK_MASK(T);                                                                           \
+        kreq_s = kreq; vreq_s = vreq;                                                         \
         kreq = kreq == NKB - 1 ? 0 : kreq + 1;                                                \
         vreq = vreq == NVB - 1 ? 0 : vreq + 1;                                                \
         if ((T) + 3 == nt - 1 && last_rows < KVT) CLAMP_LAST_TILE();    /* before M(t+1) requests the last tile */ \
         FENCE();                                                                              \
         if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);                                          \
         STAMP(0);                        /* M work */                                         \
-        DMA_WAIT(4);                                                                          \
+        DMA_WAIT(4 - ATT_DMA_IN_S);      /* tile T+1: only this segment's pieces of tile T+2 are younger */ \
         STAMP(1);                        /* DMA wait */                                       \
         BARRIER();                                                                            \
         STAMP(2);                        /* barrier at the end of M */                        \
     } while (0)
     // ---- S(t): softmax only; the first V half of tile t (requested during QK1) is complete at its end
-#define S_SEGMENT()                                                                           \
+#define S_SEGMENT(T)                                                                          \
     do {                                                                                      \
+        S_REQ(T);                                                                             \
         if (!(ATT_ABL & 32)) SOFTMAX_PHASE();                                                 \
         FENCE();                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)"                                                   \
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     REQ_PIECE(0, 0);
     REQ_PIECE(1, 0);
     M_QK(0);
-    S_SEGMENT();
+    S_SEGMENT(0);
     for (int t = 1; t < nt; ++t) {
         if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);
         STEP_PV0(0); STEP_PV0(1); STEP_PV0(2); STEP_PV0(3);
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         REQ_PIECE(1, t);
         STEP_PV1(4, 1); STEP_PV1(5, 1); STEP_PV1(6, 1); STEP_PV1(7, 1);
         M_QK(t);
-        S_SEGMENT();
+        S_SEGMENT(t);
     }
     // M(nt) = PV(nt-1)
     if (ATT_PRIO) __builtin_amdgcn_s_setprio(1);

@@ -25,6 +25,10 @@
 #include <stdlib.h>
 #include "drn_common.h"
 
+// G256S_ABL: timing-only ablation (results WRONG; shipped with 0): 8 = no epilogue math / stores
+#ifndef G256S_ABL
+#define G256S_ABL 0
+#endif
 #define TB 256
 #define BK 64
 #define HALF_BYTES (128 * BK * 2)          // 16 KiB
@@ -218,6 +222,17 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
     if (kt < nk) KSTEP(kt, 0, wx, wy);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the re-requests past the last K step: nothing lands after exit
 
+    if (G256S_ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(acc[i][mt][j][nt]));
+        return;
+    }
     // ---- epilogue (as gemm256.hip): column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -54,15 +54,29 @@ class ExchangeTimer:
     asynchronous collective.  work.wait() makes the CURRENT stream wait for RCCL's stream, so the time between the two events is
     the part of the exchange that compute did not cover ("exposed"); an exchange that has already finished costs ~0."""
 
-    def __init__(self):
+    def __init__(self, sample_every: int = 7):
+        """Only every `sample_every`-th wait of a tag is bracketed (an event pair costs ~35 us of queue time on the timing rank;
+        all waits of a forward would add ~3 ms to rank 0's step and skew the max-over-ranks time); use a stride coprime with the
+        layer count."""
+        self.sample_every = max(1, int(sample_every))
+        self.counts = {}
         self.records = []          # (tag, start_event, end_event)
 
+    def take(self, tag) -> bool:
+        c = self.counts.get(tag, 0)
+        self.counts[tag] = c + 1
+        return c % self.sample_every == 0
+
     def summary(self):
+        """tag -> waits seen, waits timed, mean exposed ms per wait (of the timed ones)."""
         out = {}
         for tag, a, b in self.records:
-            d = out.setdefault(tag, {"waits": 0, "ms_total": 0.0})
-            d["waits"] += 1
+            d = out.setdefault(tag, {"timed": 0, "ms_total": 0.0})
+            d["timed"] += 1
             d["ms_total"] += a.elapsed_time(b)
+        for tag, d in out.items():
+            d["waits"] = self.counts.get(tag, d["timed"])
+            d["ms_avg"] = d["ms_total"] / max(d["timed"], 1)
         return out
 
 
@@ -78,7 +92,7 @@ def wait_exchange(work, tag: str):
     """work.wait() (None = nothing was issued), timed when an ExchangeTimer is installed."""
     if work is None:
         return
-    if _XTIMER is None or not torch.cuda.is_available():
+    if _XTIMER is None or not torch.cuda.is_available() or not _XTIMER.take(tag):
         work.wait()
         return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -157,8 +157,11 @@ def _tok(pkg, gpu):
     return sd, pkg.CleanVAE.CleanVAE(state_dict={k: v.to(gpu) for k, v in sd.items()}, device=gpu)
 
 
-@pytest.mark.parametrize("T,H,W", [(9, 32, 32), (1, 32, 48)])
+@pytest.mark.parametrize("T,H,W", [(9, 32, 32), (1, 32, 48), (17, 288, 512)])
 def test_tokenizer_encode_decode_match_oracle(pkg, gpu, T, H, W):
+    """(17, 288, 512) is the mid-size case: the real channel counts (128-512) at spatial sizes where every conv runs many
+    128 x 128 tiles per level, temporal down / up-sampling over 3 latent frames, a 36 x 64 mid-block attention (2304 keys)."""
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     sw = pkg.synthetic_weights
     sd, vae = _tok(pkg, gpu)
     x = sw.synth_tensor("vae.x", (1, 3, T, H, W), torch.float32).to(BF)
