@@ -20,11 +20,21 @@
 //     and read again 1.25 K steps later; with that order ONE counted wait, s_waitcnt vmcnt(10) in front of every barrier,
 //     retires exactly the half-tile whose first read follows the barrier (5 half-tiles stay in flight per wave).
 //
+// Tried and rejected (round 2): (a) the same fragment reads as inline asm with hand-counted lgkmcnt waits instead of hipcc's
+// lgkmcnt(0) after two of the four barriers: +-1 % (tools/kbench.py, interleaved A/B); (b) starting the first workgroup of
+// every CU up to 31 x 0.5..4 us late so that the CUs' C-tile store bursts (256 x 128 KiB per round, ~6 % of a K = 4096 GEMM
+// with the matrix pipes idle - the `G256S_ABL=8` build) do not coincide: 1.5-10 % SLOWER, monotonically in the stagger -
+// tiles that run in lock step share their A / W panels in the XCD's L2, out of step they do not.
+//
 // Tile, LDS layout (2 stages x [A0 A1 W0 W1] x 16 KiB, 128-B rows, chunk ^ ((row>>1)&7), swizzle on the DMA source address),
 // wave -> quadrant map, blocked operand layouts and the 16-byte epilogue stores are those of gemm256.hip.
 #include <stdlib.h>
 #include "drn_common.h"
 
+// G256S_ABL: timing-only ablation (results WRONG; shipped with 0): 8 = no epilogue math / stores
+#ifndef G256S_ABL
+#define G256S_ABL 0
+#endif
 // G256S_ABL: timing-only ablation (results WRONG; shipped with 0): 8 = no epilogue math / stores
 #ifndef G256S_ABL
 #define G256S_ABL 0
@@ -222,6 +232,17 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
     if (kt < nk) KSTEP(kt, 0, wx, wy);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the re-requests past the last K step: nothing lands after exit
 
+    if (G256S_ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(acc[i][mt][j][nt]));
+        return;
+    }
     if (G256S_ABL & 8) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
