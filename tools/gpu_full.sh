@@ -10,4 +10,9 @@ timeout -k 10 600 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/ben
 rc=$?
 tail -3 gpurun_out/bench_full.err
 cat gpurun_out/bench_full.json
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 400 python bench.py --config cfg1 > gpurun_out/bench_cfg1.json 2> gpurun_out/bench_cfg1.err
+rc=$?
+tail -3 gpurun_out/bench_cfg1.err
+cat gpurun_out/bench_cfg1.json
 exit $rc
