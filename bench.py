@@ -280,6 +280,8 @@ def main():
     N.set_timer(timer)
     xtimer = pkg.parallel.ExchangeTimer() if (pg is not None and rank == 0) else None      # (also the 1-rank RCCL rehearsal)
     pkg.parallel.set_exchange_timer(xtimer)
+    if pg is not None and world == 1:
+        pkg.parallel.SINGLE_RANK_COLLECTIVES = True       # 1-rank rehearsal under torchrun: issue the RCCL calls anyway
     host_enqueue = 0.0
     t0 = time.perf_counter()
     # inside the timed region: the timed steps' AdaLN vectors, batched as generate_samples_from_batch does before its loop
