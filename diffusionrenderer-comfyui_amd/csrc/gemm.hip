@@ -221,7 +221,7 @@ int drn_gemm256_dispatch(const void* A, const void* W, void* C, int64_t M, int64
 // gemm256s.hip: the same tile, streamed schedule (tile kernel 3; takes over tile kernel 1's problems unless DRN_GEMM_STREAM=0)
 int drn_gemm256s_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                           int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                          void* stream, const int64_t* blk);
+                          void* stream, const int64_t* blk, bool persistent_ok);
 
 // gemm144.hip: 144x256x64 kernel (token bands of sequence parallelism: M = 2304 k)
 int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
@@ -233,7 +233,8 @@ int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64
 // workgroup does 56 % of the work of a 256^2 one at 0.85-1.0x its rate: DRN_GEMM144_COST = 0.64 units (measured: M = 2304
 // -> 0.79 vs 0.97 ms per DiT block; M = 18432 stays on 256^2).
 // Returns 0: 128^2, 1: 256^2, 2: 144x256.   DRN_GEMM256=0 / DRN_GEMM144=0 switch a kernel off, DRN_GEMM144=2 forces it (A/B runs).
-// drn_gemm_force_tile: -1 automatic, 0 / 1 / 2 as above (1 = the first-generation 256^2 kernel), 3 = the streamed 256^2 kernel.
+// drn_gemm_force_tile: -1 automatic, 0 / 1 / 2 as above (1 = the first-generation 256^2 kernel), 3 = the streamed 256^2 kernel
+// in its persistent form where that applies (gemm256s.hip), 4 = the streamed kernel with one workgroup per tile (= automatic).
 static int g_force_tile = -1;
 extern "C" void drn_gemm_force_tile(int tile) { g_force_tile = tile; }
 
@@ -276,8 +277,9 @@ static int gemm_launch_tile(int tile, const void* A, const void* W, void* C, int
         const char* e = getenv("DRN_GEMM_STREAM");
         stream_mode = (e && e[0] == '0') ? 0 : 1;
     }
-    if (tile == 3 || (tile == 1 && stream_mode == 1 && g_force_tile != 1))
-        return drn_gemm256s_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
+    if (tile == 3 || tile == 4 || (tile == 1 && stream_mode == 1 && g_force_tile != 1))
+        return drn_gemm256s_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk,
+                                     g_force_tile == 3);
     if (tile == 1)
         return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
     if (tile == 2)

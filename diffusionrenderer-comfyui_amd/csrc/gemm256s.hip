@@ -26,6 +26,19 @@
 // with the matrix pipes idle - the `G256S_ABL=8` build) do not coincide: 1.5-10 % SLOWER, monotonically in the stagger -
 // tiles that run in lock step share their A / W panels in the XCD's L2, out of step they do not.
 //
+// Persistent form (gemm256p_kernel; whole 256-tiles, even K/64 >= 4, more tiles than CUs): one workgroup per CU walks the tiles
+// blockIdx.x, +gridDim.x, ... and the DMA stream never stops - the last two K steps of a tile already request K steps 0 and 1 of
+// the workgroup's NEXT tile and the fragment prefetch of the last K step reads them, so a tile starts with no launch, no cold
+// prologue (~2 us of exposed DMA latency per tile before) and its MFMAs run while the previous tile's C stores drain.  The 16
+// stores of the epilogue sit in the in-order vmcnt queue BEHIND the 5 half-tiles requested before them: the first five
+// hand-overs of the new tile wait vmcnt(10 + 16), the sixth (vmcnt(10)) is the first that needs the stores to have been
+// acknowledged.  Same tile order, same summation order per tile: bit-identical to gemm256s_kernel.
+// Measured (tools/kbench.py --tiles 3,4, M = 18432): out-proj +2.6 %, MLP-up / MLP-down +-0.3 %, QKV -3.9 % (13.5 rounds of
+// tiles: the hardware dispatcher hands the last half round to whichever CUs finish first, the static walk makes half the
+// CUs do 14 tiles) - no net gain, so it is NOT the default: drn_gemm_force_tile(3) or DRN_GEMM_PERSISTENT=1 select it.
+// What that says about the one-workgroup-per-tile kernel: launch + cold prologue between tiles cost it nothing measurable
+// (the next workgroup's prologue already overlaps the previous one's store drain); non-temporal C stores (G256S_NT): +-0.5 %.
+//
 // Tile, LDS layout (2 stages x [A0 A1 W0 W1] x 16 KiB, 128-B rows, chunk ^ ((row>>1)&7), swizzle on the DMA source address),
 // wave -> quadrant map, blocked operand layouts and the 16-byte epilogue stores are those of gemm256.hip.
 #include <stdlib.h>
@@ -35,9 +48,9 @@
 #ifndef G256S_ABL
 #define G256S_ABL 0
 #endif
-// G256S_ABL: timing-only ablation (results WRONG; shipped with 0): 8 = no epilogue math / stores
-#ifndef G256S_ABL
-#define G256S_ABL 0
+// G256S_NT: C tiles stored non-temporal (a round of 256 tiles is 32 MB, the eight L2s hold 32 MB)
+#ifndef G256S_NT
+#define G256S_NT 0
 #endif
 #define TB 256
 #define BK 64
@@ -52,106 +65,65 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
-                                                          const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
-                                                          int abc, int64_t abs_, int cbc, int64_t cbs) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * STAGE_BYTES, the ONLY LDS object
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = (wave >> 1) & 1;            // which 64 rows of each A half
-    const int wc = (wave & 1) | ((wave >> 2) << 1);    // which 32 rows (output columns) of each W half: 0..3
-
-    const int tiles_m = (int)((M + TB - 1) / TB);
-    const int tiles_n = (int)((N + TB - 1) / TB);
-    const int nwg = tiles_m * tiles_n;
-    int pid;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+// workgroup index (dispatch order; XCD = index & 7) -> tile: XCD-contiguous chunks, GROUP tile rows per L2 band
+static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, int tiles_n, int GROUP, int64_t& m0, int64_t& n0) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int width = GROUP * tiles_n;
     const int group_id = pid / width;
     const int first_m = group_id * GROUP;
     const int gsz = min(tiles_m - first_m, GROUP);
-    const int tm = first_m + (pid % width) % gsz;
-    const int tn = (pid % width) / gsz;
-    const int64_t m0 = (int64_t)tm * TB, n0 = (int64_t)tn * TB;
+    m0 = (int64_t)(first_m + (pid % width) % gsz) * TB;
+    n0 = (int64_t)((pid % width) / gsz) * TB;
+}
 
-    // ---- DMA source pointers: this wave's 2 pieces (16 rows) of each half-tile
-    const bf16_t* gsrc[4][2];        // [A0 A1 W0 W1][piece]
-#pragma unroll
-    for (int h = 0; h < 4; ++h)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = (wave * 2 + p) * 8 + (lane >> 3);           // row inside the half-tile, 0..127
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            if (h < 2) {
-                int64_t row = m0 + h * 128 + r;
-                if (row > M - 1) row = M - 1;
-                gsrc[h][p] = A + row * lda + c * 8;
-            } else {
-                int64_t row = n0 + (h - 2) * 128 + r;
-                if (row > N - 1) row = N - 1;
-                gsrc[h][p] = W + row * ldw + c * 8;
-            }
-        }
-    const int dma_off = wave * 2048;                                   // this wave's 2 KiB inside a half-tile region
-    const int nk = (int)(K / BK);
-    // blocked operand layouts (drn_gemm_bf16_blocked), see gemm256.hip
-#define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
-    const int64_t c_tile_off = (n0 >> cbc) * cbs + (n0 & ((1ll << cbc) - 1)) - n0;
-    // half-tile H of K step KT (steps past the end re-request the last one into a region nobody reads: the wait counts stay uniform)
-#define DMA(H, KT, S)                                                                                                  \
+// this wave's 2 pieces (16 rows) of each half-tile [A0 A1 W0 W1] of the tile at (m0, n0)
+#define SET_SRC(M0, N0)                                                                                                \
     do {                                                                                                               \
-        const int kt_ = min((int)(KT), nk - 1);                                                                        \
+        _Pragma("unroll") for (int h = 0; h < 4; ++h)                                                                  \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                            \
+                const int r = (wave * 2 + p) * 8 + (lane >> 3);          /* row inside the half-tile, 0..127 */        \
+                const int c = (lane & 7) ^ ((r >> 1) & 7);                                                             \
+                if (h < 2) {                                                                                           \
+                    int64_t row = (M0) + h * 128 + r;                                                                  \
+                    if (row > M - 1) row = M - 1;                                                                      \
+                    gsrc[h][p] = A + row * lda + c * 8;                                                                \
+                } else {                                                                                               \
+                    int64_t row = (N0) + (h - 2) * 128 + r;                                                            \
+                    if (row > N - 1) row = N - 1;                                                                      \
+                    gsrc[h][p] = W + row * ldw + c * 8;                                                                \
+                }                                                                                                      \
+            }                                                                                                          \
+    } while (0)
+
+// blocked operand layouts (drn_gemm_bf16_blocked), see gemm256.hip
+#define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
+// half-tile H of K step KD (of the tile gsrc points at) into stage S
+#define DMA(H, KD, S)                                                                                                  \
+    do {                                                                                                               \
+        const int kt_ = (int)(KD);                                                                                     \
         char* dst_ = smem + (S) * STAGE_BYTES + (H) * HALF_BYTES + dma_off;                                            \
         const int64_t ko_ = (H) < 2 ? A_KOFF(kt_) : (int64_t)kt_ * BK;                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][0] + ko_), (lptr_t)dst_, 16, 0, 0);                          \
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][1] + ko_), (lptr_t)(dst_ + 1024), 16, 0, 0);                 \
     } while (0)
 
-    // ---- fragment read offsets inside a half-tile region (k-substep 1 = offset ^ 64)
-    const int fr = lane & 15, fq = lane >> 4;
-    int offa, offw;
-    {
-        const int ra = wr * 64 + fr;                                   // + 16 * mt
-        const int rw = wc * 32 + fr;                                   // + 16 * nt
-        offa = ra * 128 + ((fq ^ ((ra >> 1) & 7)) << 4);
-        offw = rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);
-    }
 #define LD_A(S, I, MT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + (S) * STAGE_BYTES + (I) * HALF_BYTES + ((KS) ? (offa ^ 64) : offa) + (MT) * 2048))
 #define LD_W(S, J, NT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + (S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES + ((KS) ? (offw ^ 64) : offw) + (NT) * 2048))
-
-    f32x4_t acc[2][4][2][2];       // [i][mt][j][nt]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[i][mt][j][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    bf16x8_t af[4][2], wx[2][2], wy[2][2];   // A fragments [mt][ks]; the two W fragment buffers [nt][ks] (roles swap per K step)
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MM(I, MT, J, NT, KS, WF)                                                                                    \
     acc[I][MT][J][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[NT][KS], af[MT][KS], acc[I][MT][J][NT], 0, 0, 0)
-    // end of a group: the half-tile whose first read follows has landed (own pieces: 5 half-tiles = 10 younger pieces may fly)
-#define HANDOVER()                                                                                                  \
+// end of a group: the half-tile whose first read follows has landed (own pieces: 5 half-tiles = 10 younger pieces may fly;
+// VM = 10, or 10 + the stores of an epilogue that were issued after that half-tile's request)
+#define HANDOVER(VM)                                                                                                \
     do {                                                                                                            \
         FENCE();                                                                                                    \
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                           \
+        asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                                      \
         __builtin_amdgcn_s_barrier();                                                                               \
         FENCE();                                                                                                    \
     } while (0)
-    // one (mt, ks) slot of a group: the two MFMAs (nt = 0, 1) that read af[MT][KS], then that slot's share of the prefetch
+// one (mt, ks) slot of a group: the two MFMAs (nt = 0, 1) that read af[MT][KS], then that slot's share of the prefetch
 #define SLOT(I, J, MT, KS, WF, PREFETCH)                                                                            \
     do {                                                                                                            \
         MM(I, MT, J, 0, KS, WF);                                                                                    \
@@ -159,79 +131,108 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
         PREFETCH;                                                                                                   \
         FENCE();                                                                                                    \
     } while (0)
-    // K step KT (stage S = KT & 1, a literal) with W0(KT) in WA: groups 1..4.  On exit af = A0(KT+1), WB = W0(KT+1).
-#define KSTEP(KT, S, WA, WB)                                                                                        \
+// K step in stage S (a literal) with W0 of this step in WA: groups 1..4; the DMA of the step two ahead (k index KD of the tile
+// gsrc points at) goes into the regions they free.  On exit af = A0 and WB = W0 of the next step.  V1..V4: the hand-over waits.
+#define KSTEP(S, WA, WB, KD, V1, V2, V3, V4)                                                                        \
     do {                                                                                                            \
-        /* group 1 (A0,W0): request W1(KT) -> WB; DMA W0(KT+2) */                                                   \
+        /* group 1 (A0,W0): request W1 -> WB; DMA W0(+2) */                                                         \
         SLOT(0, 0, 0, 0, WA, WB[0][0] = LD_W(S, 1, 0, 0));                                                          \
         SLOT(0, 0, 1, 0, WA, WB[1][0] = LD_W(S, 1, 1, 0));                                                          \
         SLOT(0, 0, 2, 0, WA, WB[0][1] = LD_W(S, 1, 0, 1));                                                          \
         SLOT(0, 0, 3, 0, WA, WB[1][1] = LD_W(S, 1, 1, 1));                                                          \
-        DMA(H_W0, (KT) + 2, S);                                                                                     \
+        DMA(H_W0, KD, S);                                                                                           \
         FENCE();                                                                                                    \
         SLOT(0, 0, 0, 1, WA, (void)0); SLOT(0, 0, 1, 1, WA, (void)0); SLOT(0, 0, 2, 1, WA, (void)0); SLOT(0, 0, 3, 1, WA, (void)0); \
-        HANDOVER();                      /* A1(KT) has landed */                                                    \
-        /* group 2 (A0,W1): request A1(KT) -> af as its A0 entries die; DMA A0(KT+2) */                             \
+        HANDOVER(V1);                    /* A1 of this step has landed */                                           \
+        /* group 2 (A0,W1): request A1 -> af as its A0 entries die; DMA A0(+2) */                                   \
         SLOT(0, 1, 0, 0, WB, af[0][0] = LD_A(S, 1, 0, 0));                                                          \
         SLOT(0, 1, 1, 0, WB, af[1][0] = LD_A(S, 1, 1, 0));                                                          \
         SLOT(0, 1, 2, 0, WB, af[2][0] = LD_A(S, 1, 2, 0));                                                          \
         SLOT(0, 1, 3, 0, WB, af[3][0] = LD_A(S, 1, 3, 0));                                                          \
-        DMA(H_A0, (KT) + 2, S);                                                                                     \
+        DMA(H_A0, KD, S);                                                                                           \
         FENCE();                                                                                                    \
         SLOT(0, 1, 0, 1, WB, af[0][1] = LD_A(S, 1, 0, 1));                                                          \
         SLOT(0, 1, 1, 1, WB, af[1][1] = LD_A(S, 1, 1, 1));                                                          \
         SLOT(0, 1, 2, 1, WB, af[2][1] = LD_A(S, 1, 2, 1));                                                          \
         SLOT(0, 1, 3, 1, WB, af[3][1] = LD_A(S, 1, 3, 1));                                                          \
-        HANDOVER();                      /* W0(KT+1) has landed */                                                  \
-        /* group 3 (A1,W1): request W0(KT+1) -> WB as it dies; DMA W1(KT+2) */                                      \
+        HANDOVER(V2);                    /* W0 of the next step has landed */                                       \
+        /* group 3 (A1,W1): request W0(+1) -> WB as it dies; DMA W1(+2) */                                          \
         SLOT(1, 1, 0, 0, WB, (void)0); SLOT(1, 1, 1, 0, WB, (void)0); SLOT(1, 1, 2, 0, WB, (void)0);                \
         SLOT(1, 1, 3, 0, WB, (WB[0][0] = LD_W((S) ^ 1, 0, 0, 0), WB[1][0] = LD_W((S) ^ 1, 0, 1, 0)));               \
-        DMA(H_W1, (KT) + 2, S);                                                                                     \
+        DMA(H_W1, KD, S);                                                                                           \
         FENCE();                                                                                                    \
         SLOT(1, 1, 0, 1, WB, (void)0); SLOT(1, 1, 1, 1, WB, (void)0); SLOT(1, 1, 2, 1, WB, (void)0);                \
         SLOT(1, 1, 3, 1, WB, (WB[0][1] = LD_W((S) ^ 1, 0, 0, 1), WB[1][1] = LD_W((S) ^ 1, 0, 1, 1)));               \
-        HANDOVER();                      /* A0(KT+1) has landed */                                                  \
-        /* group 4 (A1,W0): request A0(KT+1) -> af as its A1 entries die; DMA A1(KT+2) */                           \
+        HANDOVER(V3);                    /* A0 of the next step has landed */                                       \
+        /* group 4 (A1,W0): request A0(+1) -> af as its A1 entries die; DMA A1(+2) */                               \
         SLOT(1, 0, 0, 0, WA, af[0][0] = LD_A((S) ^ 1, 0, 0, 0));                                                    \
         SLOT(1, 0, 1, 0, WA, af[1][0] = LD_A((S) ^ 1, 0, 1, 0));                                                    \
         SLOT(1, 0, 2, 0, WA, af[2][0] = LD_A((S) ^ 1, 0, 2, 0));                                                    \
         SLOT(1, 0, 3, 0, WA, af[3][0] = LD_A((S) ^ 1, 0, 3, 0));                                                    \
-        DMA(H_A1, (KT) + 2, S);                                                                                     \
+        DMA(H_A1, KD, S);                                                                                           \
         FENCE();                                                                                                    \
         SLOT(1, 0, 0, 1, WA, af[0][1] = LD_A((S) ^ 1, 0, 0, 1));                                                    \
         SLOT(1, 0, 1, 1, WA, af[1][1] = LD_A((S) ^ 1, 0, 1, 1));                                                    \
         SLOT(1, 0, 2, 1, WA, af[2][1] = LD_A((S) ^ 1, 0, 2, 1));                                                    \
         SLOT(1, 0, 3, 1, WA, af[3][1] = LD_A((S) ^ 1, 0, 3, 1));                                                    \
-        HANDOVER();                      /* W1(KT+1) has landed */                                                  \
+        HANDOVER(V4);                    /* W1 of the next step has landed */                                       \
     } while (0)
 
-    // ---- prologue: K steps 0 and 1 requested in the steady-state order; W0(0) / A0(0) go to registers, W1(0) becomes visible
-    DMA(H_W0, 0, 0); DMA(H_A0, 0, 0); DMA(H_W1, 0, 0); DMA(H_A1, 0, 0);
-    DMA(H_W0, 1, 1); DMA(H_A0, 1, 1); DMA(H_W1, 1, 1); DMA(H_A1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // W0(0), A0(0)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wx[nt][ks] = LD_W(0, 0, nt, ks);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[mt][ks] = LD_A(0, 0, mt, ks);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    FENCE();
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                  // W1(0): read in group 1 of K step 0
-    __builtin_amdgcn_s_barrier();                                      // (and every wave holds W0(0) / A0(0): their regions are free)
-    FENCE();
+// prologue of a cold start: K steps 0 and 1 requested in the steady-state order; W0(0) / A0(0) go to registers, W1(0) visible
+#define PROLOGUE()                                                                                                  \
+    do {                                                                                                            \
+        DMA(H_W0, 0, 0); DMA(H_A0, 0, 0); DMA(H_W1, 0, 0); DMA(H_A1, 0, 0);                                         \
+        DMA(H_W0, k_second, 1); DMA(H_A0, k_second, 1); DMA(H_W1, k_second, 1); DMA(H_A1, k_second, 1);             \
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  /* W0(0), A0(0) */                       \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                            \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) wx[nt][ks] = LD_W(0, 0, nt, ks);                       \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) af[mt][ks] = LD_A(0, 0, mt, ks);                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+        FENCE();                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                  /* W1(0): read in group 1 of K step 0 */ \
+        __builtin_amdgcn_s_barrier();              /* (and every wave holds W0(0) / A0(0): their regions are free) */ \
+        FENCE();                                                                                                    \
+    } while (0)
 
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        KSTEP(kt, 0, wx, wy);
-        KSTEP(kt + 1, 1, wy, wx);
-    }
-    if (kt < nk) KSTEP(kt, 0, wx, wy);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the re-requests past the last K step: nothing lands after exit
+#define ZERO_ACC()                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[i][mt][j][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}
 
+// per-thread constants of both kernels
+#define THREAD_SETUP()                                                                                              \
+    extern __shared__ __attribute__((aligned(1024))) char smem[];     /* 2 * STAGE_BYTES, the ONLY LDS object */     \
+    const int tid = threadIdx.x;                                                                                    \
+    const int lane = tid & 63;                                                                                      \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                      \
+    const int wr = (wave >> 1) & 1;            /* which 64 rows of each A half */                                   \
+    const int wc = (wave & 1) | ((wave >> 2) << 1);    /* which 32 rows (output columns) of each W half: 0..3 */     \
+    const int tiles_m = (int)((M + TB - 1) / TB);                                                                   \
+    const int tiles_n = (int)((N + TB - 1) / TB);                                                                   \
+    const int nwg = tiles_m * tiles_n;                                                                              \
+    const int dma_off = wave * 2048;                                   /* this wave's 2 KiB inside a half-tile region */ \
+    const int nk = (int)(K / BK);                                                                                   \
+    /* fragment read offsets inside a half-tile region (k-substep 1 = offset ^ 64) */                               \
+    const int fr = lane & 15, fq = lane >> 4;                                                                       \
+    int offa, offw;                                                                                                 \
+    {                                                                                                               \
+        const int ra = wr * 64 + fr;                                   /* + 16 * mt */                              \
+        const int rw = wc * 32 + fr;                                   /* + 16 * nt */                              \
+        offa = ra * 128 + ((fq ^ ((ra >> 1) & 7)) << 4);                                                            \
+        offw = rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);                                                            \
+    }                                                                                                               \
+    const bf16_t* gsrc[4][2];        /* DMA sources [A0 A1 W0 W1][piece] */                                         \
+    f32x4_t acc[2][4][2][2];         /* [i][mt][j][nt] */                                                           \
+    bf16x8_t af[4][2], wx[2][2], wy[2][2]   /* A fragments [mt][ks]; the two W fragment buffers [nt][ks] (roles swap per K step) */
+
+// epilogue (as gemm256.hip): column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores (16 per lane)
+template <int EPI>
+static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf16_t* C, int64_t M, int64_t N, int64_t ldc,
+                                                  const bf16_t* __restrict__ gate, const bf16_t* R, int64_t ldr, int64_t rpb,
+                                                  int cbc, int64_t cbs, int64_t m0, int64_t n0, int wr, int wc, int fr, int fq) {
     if (G256S_ABL & 8) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -243,32 +244,47 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
                     for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(acc[i][mt][j][nt]));
         return;
     }
-    if (G256S_ABL & 8) {
+    const int64_t c_tile_off = (n0 >> cbc) * cbs + (n0 & ((1ll << cbc) - 1)) - n0;
+    // every address below derives from these two: defined HERE, so that none of the address arithmetic is hoisted out of the
+    // persistent kernel's tile loop into registers that stay live through the K loop (it spilled there)
+    asm volatile("" : "+v"(fr), "+v"(fq));
+    const int64_t b_tile = (EPI == DRN_EPI_GATE_RES) ? (int64_t)((uint32_t)m0 / (uint32_t)rpb) : 0;      // launcher: M < 2^31
+    const bool one_clip = m0 + TB <= (b_tile + 1) * rpb;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        // gate / residual of this half first, all 32 loads in flight at once: issued one (mt, j) unit at a time in front of that
+        // unit's store they were 16 dependent memory round trips per tile (the residual may alias C - in-place x += g * y - so
+        // hipcc cannot move a load above the previous unit's store by itself).  Every element is loaded and stored by lanes of
+        // the same wave (the permlane16 partner), and a wave's loads of a half all precede its stores of that half.
+        uint2 g2[4][2][2], r2[4][2][2];
+        if (EPI == DRN_EPI_GATE_RES) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt) {
+                const int64_t m_raw = m0 + i * 128 + wr * 64 + mt * 16 + fr;
+                const int64_t m = m_raw < M ? m_raw : M - 1;
+                // the tile's clip: one scalar division per tile unless the tile straddles two clips (64-bit vector divisions
+                // are ~100 instructions each)
+                const int64_t b = one_clip ? b_tile : (int64_t)((uint32_t)m / (uint32_t)rpb);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(acc[i][mt][j][nt]));
-        return;
-    }
-    // ---- epilogue (as gemm256.hip): column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + fq * 4;
+                        g2[mt][j][nt] = *reinterpret_cast<const uint2*>(gate + b * N + n);
+                        r2[mt][j][nt] = *reinterpret_cast<const uint2*>(R + m * ldr + n);
+                    }
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int64_t m_raw = m0 + i * 128 + wr * 64 + mt * 16 + fr;
             const bool m_ok = m_raw < M;
             const int64_t m = m_ok ? m_raw : M - 1;
-            const int64_t b = (EPI == DRN_EPI_GATE_RES) ? m / rpb : 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 uint2 o[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + fq * 4;
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][mt][j][nt][r]);
@@ -276,10 +292,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
                     } else if (EPI == DRN_EPI_GATE_RES) {
-                        const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);
-                        const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);
-                        const float g[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
-                        const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+                        const uint2 gg = g2[mt][j][nt], rr = r2[mt][j][nt];
+                        const float g[4] = {bflo(gg.x), bfhi(gg.x), bflo(gg.y), bfhi(gg.y)};
+                        const float x[4] = {bflo(rr.x), bfhi(rr.x), bflo(rr.y), bfhi(rr.y)};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);
                     }
@@ -289,30 +304,171 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
                 const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
                 const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
                 const int64_t n8 = n0 + j * 128 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
-                if (m_ok && n8 < N)
-                    *reinterpret_cast<uint4*>(C + m * ldc + n8 + c_tile_off) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (m_ok && n8 < N) {
+                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                    const u32x4_t val = {sx[0], sy[0], sx[1], sy[1]};
+                    u32x4_t* dst = reinterpret_cast<u32x4_t*>(C + m * ldc + n8 + c_tile_off);
+                    if (G256S_NT) __builtin_nontemporal_store(val, dst);
+                    else *dst = val;
+                }
             }
         }
+    }
 }
+#define STORES_PER_TILE 16          // vector-memory stores per lane in store_tile (whole tiles): part of the vmcnt arithmetic
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
+                                                          const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
+                                                          int abc, int64_t abs_, int cbc, int64_t cbs) {
+    THREAD_SETUP();
+    int64_t m0, n0;
+    tile_of(blockIdx.x, nwg, tiles_m, tiles_n, GROUP, m0, n0);
+    SET_SRC(m0, n0);
+    ZERO_ACC();
+    const int k_second = min(1, nk - 1);
+    PROLOGUE();
+    // steps past the end re-request the last one into a region nobody reads: the wait counts stay uniform
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        KSTEP(0, wx, wy, min(kt + 2, nk - 1), 10, 10, 10, 10);
+        KSTEP(1, wy, wx, min(kt + 3, nk - 1), 10, 10, 10, 10);
+    }
+    if (kt < nk) KSTEP(0, wx, wy, nk - 1, 10, 10, 10, 10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the re-requests past the last K step: nothing lands after exit
+    store_tile<EPI>(acc, C, M, N, ldc, gate, R, ldr, rpb, cbc, cbs, m0, n0, wr, wc, fr, fq);
+}
+
+// persistent form: see the header.  Launcher guarantees M % 256 == 0, N % 256 == 0 (every lane stores: STORES_PER_TILE holds),
+// nk even and >= 4, gridDim.x <= number of tiles.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
+                                                          const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
+                                                          int abc, int64_t abs_, int cbc, int64_t cbs) {
+    THREAD_SETUP();
+    (void)gsrc;
+    // DMA addresses: a scalar base per (tile, half-tile, K step) + one 32-bit lane offset per operand and piece (whole tiles:
+    // no row clamp), the `global_load_lds saddr + voffset` form - 4 address registers instead of 16, no 64-bit vector adds
+    uint32_t voffa[2], voffw[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int rl = p * 8 + (lane >> 3);                              // row inside this wave's 16 rows of a half-tile
+        const int c = (lane & 7) ^ ((rl >> 1) & 7);                      // (wave * 16 is a multiple of 16: no part in the swizzle)
+        voffa[p] = (uint32_t)((rl * lda + c * 8) * 2);
+        voffw[p] = (uint32_t)((rl * ldw + c * 8) * 2);
+    }
+#undef DMA
+#define DMA(H, KD, S)                                                                                                  \
+    do {                                                                                                               \
+        const int kt_ = (int)(KD);                                                                                     \
+        char* dst_ = smem + (S) * STAGE_BYTES + (H) * HALF_BYTES + dma_off;                                            \
+        const char* sb_ = (H) < 2 ? sa_tile + (((int64_t)((H) * 128) * lda + A_KOFF(kt_)) << 1)                        \
+                                  : sw_tile + (((int64_t)(((H) - 2) * 128) * ldw + (int64_t)kt_ * BK) << 1);            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + ((H) < 2 ? voffa[0] : voffw[0])), (lptr_t)dst_, 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + ((H) < 2 ? voffa[1] : voffw[1])), (lptr_t)(dst_ + 1024), 16, 0, 0); \
+    } while (0)
+#define SET_TILE(M0, N0)                                                                                               \
+    do {                                                                                                               \
+        sa_tile = reinterpret_cast<const char*>(A + ((M0) + wave * 16) * lda);                                         \
+        sw_tile = reinterpret_cast<const char*>(W + ((N0) + wave * 16) * ldw);                                         \
+    } while (0)
+    const char *sa_tile, *sw_tile;
+    int vb = blockIdx.x;
+    int64_t m0, n0;
+    tile_of(vb, nwg, tiles_m, tiles_n, GROUP, m0, n0);
+    SET_TILE(m0, n0);
+    ZERO_ACC();
+    const int k_second = 1;
+    PROLOGUE();
+    KSTEP(0, wx, wy, 2, 10, 10, 10, 10);
+    KSTEP(1, wy, wx, 3, 10, 10, 10, 10);
+    for (;;) {
+        for (int kt = 2; kt < nk - 2; kt += 2) {
+            KSTEP(0, wx, wy, kt + 2, 10, 10, 10, 10);
+            KSTEP(1, wy, wx, kt + 3, 10, 10, 10, 10);
+        }
+        // every request of this tile is out: the DMA stream moves on to the next tile (or re-requests this one's last step)
+        const int vn = vb + (int)gridDim.x;
+        const bool more = vn < nwg;
+        int64_t m1 = m0, n1 = n0;
+        int k0 = nk - 1, k1 = nk - 1;
+        if (more) {
+            tile_of(vn, nwg, tiles_m, tiles_n, GROUP, m1, n1);
+            SET_TILE(m1, n1);
+            k0 = 0;
+            k1 = 1;
+        }
+        KSTEP(0, wx, wy, k0, 10, 10, 10, 10);
+        KSTEP(1, wy, wx, k1, 10, 10, 10, 10);          // its last two hand-overs: W0(0) / A0(0) of the next tile have landed
+        FENCE();
+        store_tile<EPI>(acc, C, M, N, ldc, gate, R, ldr, rpb, cbc, cbs, m0, n0, wr, wc, fr, fq);
+        FENCE();
+        if (!more) break;
+        ZERO_ACC();
+        m0 = m1;
+        n0 = n1;
+        vb = vn;
+        // the fragments of K step 0 are read again here rather than kept across the epilogue (48 registers it needs); the barrier
+        // keeps a wave that runs ahead from re-filling those regions (DMA of K step 2, groups 1 / 2) under a slower wave's reads
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wx[nt][ks] = LD_W(0, 0, nt, ks);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = LD_A(0, 0, mt, ks);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FENCE();
+        // the stores are younger than the half-tiles the first five hand-overs wait for
+        KSTEP(0, wx, wy, 2, 26, 26, 26, 26);
+        KSTEP(1, wy, wx, 3, 26, 10, 10, 10);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+static_assert(STORES_PER_TILE == 16, "the vmcnt(26) hand-overs above are 10 + STORES_PER_TILE");
+
+static int g_cus = 0;
 
 template <int EPI>
 static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                       int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
-                      const int64_t* blk) {
+                      const int64_t* blk, bool persistent_ok) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const int64_t tiles = ((M + TB - 1) / TB) * ((N + TB - 1) / TB);
-    if (tiles >= (1ll << 31)) return DRN_EINVAL;
-    static int group = 0;
+    if (tiles >= (1ll << 31) || M >= (1ll << 31)) return DRN_EINVAL;
+    if (rpb > M || rpb <= 0) rpb = M;                      // (32-bit row / rows_per_batch arithmetic in the epilogue)
+    static int group = 0, persistent = -1;
     if (group == 0) {
         const char* e = getenv("DRN_GEMM_GROUP");          // tile-rows per L2 band (A/B experiments)
         group = e ? atoi(e) : 4;
         if (group < 1) group = 4;
+        e = getenv("DRN_GEMM_PERSISTENT");                 // 1: persistent form wherever it applies; default: only when forced
+        persistent = e ? atoi(e) : 0;                      // (drn_gemm_force_tile(3)) - see the header for the measurement
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            g_cus = 0;
+    }
+    const int64_t nk = K / BK;
+    if ((persistent || persistent_ok) && g_cus >= 8 && g_cus % 8 == 0 && tiles > g_cus && M % TB == 0 && N % TB == 0 && nk >= 4 && nk % 2 == 0) {
+        gemm256p_kernel<EPI><<<dim3((unsigned)g_cus), dim3(512), 2 * STAGE_BYTES, st>>>(
+            (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate,
+            (const bf16_t*)residual, ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
+        return drn_launch_status();
     }
     gemm256s_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
@@ -323,12 +479,12 @@ static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t 
 // called from gemm.hip (tile kernel 3); arguments already validated there
 int drn_gemm256s_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                           int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                          void* stream, const int64_t* blk) {
+                          void* stream, const int64_t* blk, bool persistent_ok) {
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case DRN_EPI_NONE: return launch256s<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
-        case DRN_EPI_GELU: return launch256s<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
-        case DRN_EPI_GATE_RES: return launch256s<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_NONE: return launch256s<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, persistent_ok);
+        case DRN_EPI_GELU: return launch256s<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, persistent_ok);
+        case DRN_EPI_GATE_RES: return launch256s<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, persistent_ok);
         default: return DRN_EINVAL;
     }
 }

@@ -395,6 +395,63 @@ def test_gemm256_streamed_identity_and_equals_first_generation(pkg, gpu):
     assert torch.equal(outs[1][1], outs[3][1])
 
 
+@pytest.mark.parametrize("M,N,K,epi,rpb", [(4352, 4096, 256, 0, None), (4352, 4096, 384, 1, None), (8704, 2048, 1024, 2, None),
+                                           (4352, 4096, 256, 2, 2176), (18432, 4096, 512, 2, None)])
+def test_gemm256_persistent_equals_one_workgroup_per_tile(pkg, gpu, M, N, K, epi, rpb):
+    """More 256-tiles than CUs: the streamed kernel runs persistent (a workgroup walks several tiles, the DMA stream and the
+    vmcnt arithmetic cross the tile boundary, 4 / 6 / 8 / 16 K steps).  Bit-identical to one workgroup per tile (force_tile 4)
+    and within the usual bound of the fp32 product; gated residual in place (C aliases R), also with a tile that straddles
+    two clips (rows_per_batch = 8.5 tiles)."""
+    lib = pkg.native.load_library()
+    a, w = rnd((M, K), gpu, seed=130), rnd((N, K), gpu, K ** -0.5, seed=131)
+    lin = (a.float() @ w.float().t()).to(BF)
+    B = M // rpb if rpb else 1
+    x, gate = rnd((M, N), gpu, seed=132), rnd((B, N), gpu, 0.5, seed=133)
+    outs = {}
+    for tile in (3, 4):
+        lib.drn_gemm_force_tile(tile)
+        try:
+            if epi == 2:
+                out = x.clone()
+                pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out, rows_per_batch=rpb)
+            else:
+                out = pkg.native.gemm(a, w, epilogue=epi)
+            outs[tile] = out
+        finally:
+            lib.drn_gemm_force_tile(-1)
+    assert torch.equal(outs[3], outs[4])
+    mag = None
+    if epi == 0:
+        ref = lin
+    elif epi == 1:
+        ref = F.gelu(lin.cpu()).to(gpu)
+    else:
+        g = gate.repeat_interleave(M // B, dim=0)
+        ref = x + g * lin
+        mag = torch.maximum(x.abs(), (g * lin).abs())
+    ok, msg = ulp_diff_ok(outs[3], ref, max_ulp=2, frac_exact=0.97, mag=mag)
+    assert ok, msg
+
+
+def test_gemm256_persistent_blocked_layouts(pkg, gpu):
+    """The rank-major plane layouts of the sequence-parallel exchange through the persistent form."""
+    lib = pkg.native.load_library()
+    M, N, K, P = 4352, 4096, 512, 4
+    a, w = rnd((M, K), gpu, seed=140), rnd((N, K), gpu, K ** -0.5, seed=141)
+    a_pl = a.view(M, P, K // P).permute(1, 0, 2).contiguous()
+    outs = {}
+    for tile in (3, 4):
+        lib.drn_gemm_force_tile(tile)
+        try:
+            c_pl = torch.empty(P, M, N // P, dtype=BF, device=gpu)
+            pkg.native.gemm_blocked(a_pl, w, c_pl, M, a_planes=True, c_planes=True)
+            outs[tile] = (c_pl, pkg.native.gemm(a, w))
+        finally:
+            lib.drn_gemm_force_tile(-1)
+    assert torch.equal(outs[3][0], outs[4][0]) and torch.equal(outs[3][1], outs[4][1])
+    assert torch.equal(outs[3][0].permute(1, 0, 2).reshape(M, N), outs[3][1])
+
+
 # ------------------------------------------------------------------------------------------------ 144x256 GEMM (token bands, M = 2304 k)
 @pytest.mark.parametrize("M,N,K,epi", [(144, 256, 64, 0), (2304, 256, 128, 0), (1000, 512, 192, 0), (2304, 768, 256, 1),
                                        (1537, 256, 320, 2), (2304, 4096, 1024, 2), (150, 256, 4096, 0)])
