@@ -16,6 +16,7 @@
 //
 // Tile / wave layout / LDS swizzle are those of gemm.hip (128x128x64, 4 waves, 16x16x32 bf16 MFMA,
 // D = Wfrag x Afrag so a lane owns 4 consecutive output channels of one position).
+#include <stdlib.h>
 #include "drn_common.h"
 
 #define BM 128
@@ -27,17 +28,7 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-struct ConvGeom {
-    // output positions
-    int To, Ho, Wo;
-    // input addressing: frame pitch (in positions) and row pitch, origin of the un-padded image
-    int T, Hp, Wp, ih0, iw0;
-    int kT, kH, kW, sT, sH, sW;
-    int t_off;            // ti = max(to*sT + kt - t_off, 0)
-    int pad;              // spatial padding of the conv (0 or 1): hi = ho*sH + kh - pad
-    // output addressing
-    int oHp, oWp, oh0, ow0;
-};
+#include "conv_geom.h"
 
 template <bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
@@ -191,6 +182,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const bf16_t* __rest
     }
 }
 
+// conv256s.hip: the streamed 256x256 kernel for the big convolutions
+bool drn_conv256s_ok(const ConvGeom& g, int C, int N, int64_t ldc, int64_t ldr, bool has_residual, bool out_f32, const void* y,
+                     const void* residual);
+int drn_conv256s_launch(const void* x, const void* w, const void* bias, void* y, const void* residual, const ConvGeom& g, int C,
+                        int N, int64_t ldw, int64_t ldc, int64_t ldr, void* stream);
+
+// drn_conv_force_tile: -1 automatic, 0 the 128x128 kernel always, 1 the 256x256 streamed kernel wherever it can run (also
+// below its size threshold).  drn_conv_last_tile: which kernel the last drn_conv3d_igemm call launched (tests / tools).
+static int g_conv_force = -1, g_conv_last = -1;
+extern "C" void drn_conv_force_tile(int tile) { g_conv_force = tile; }
+extern "C" int drn_conv_last_tile(void) { return g_conv_last; }
+
 extern "C" int drn_conv3d_igemm(const void* x, const void* w, const void* bias, void* y, const void* residual,
                                 int T, int H, int W, int C, int in_halo, int N, int kT, int kH, int kW, int sT, int sH,
                                 int sW, int pad, int t_off, int To, int Ho, int Wo, int out_halo, int64_t ldc,
@@ -214,6 +217,21 @@ extern "C" int drn_conv3d_igemm(const void* x, const void* w, const void* bias, 
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     DRN_CHECK_ARG(tiles < (1ll << 31));
     const int64_t ldw = (int64_t)kT * kH * kW * C;
+    if (g_conv_force != 0) {
+        static int mode = -1;
+        if (mode < 0) {
+            const char* e = getenv("DRN_CONV256");             // 0: off (A/B runs)
+            mode = (e && e[0] == '0') ? 0 : 1;
+        }
+        const bool can = drn_conv256s_ok(g, C, N, ldc, ldr, residual != nullptr, out_f32 != 0, y, residual);
+        const bool small_ok = g_conv_force == 1 && !out_f32 && N % 256 == 0 && C % 64 == 0 && ldc % 8 == 0 &&
+                              ((uintptr_t)y & 15) == 0 && (int64_t)T * g.Hp * g.Wp * C * 2 < (1ll << 32);
+        if ((mode == 1 && can) || small_ok) {
+            g_conv_last = 1;
+            return drn_conv256s_launch(x, w, bias, y, residual, g, C, N, ldw, ldc, ldr, stream);
+        }
+    }
+    g_conv_last = 0;
     dim3 grid((unsigned)tiles), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (out_f32)

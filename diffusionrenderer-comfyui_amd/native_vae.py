@@ -10,6 +10,8 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 N.SIGNATURES.update({
     "drn_conv3d_igemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                          _L, _L, _I, _F, _P],
+    "drn_conv_force_tile": [_I],
+    "drn_conv_last_tile": [],
     "drn_groupnorm_silu": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "drn_groupnorm_workspace_bytes": [_I],
     "drn_groupnorm_stats": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -189,6 +189,12 @@ int drn_conv3d_igemm(const void* x, const void* w, const void* bias, void* y, co
                      int kT, int kH, int kW, int sT, int sH, int sW, int pad, int t_off,
                      int To, int Ho, int Wo, int out_halo, int64_t ldc, int64_t ldr,
                      int out_f32, float alpha, void* stream);
+/* tuning hooks (no reference counterpart): the big convolutions (N % 256 == 0, bf16 output, >= 192 tiles of 256 positions x
+ * 256 channels, input < 4 GiB) run on the streamed 256x256 kernel (csrc/conv256s.hip), everything else on the 128x128 one;
+ * results are bit-identical.  drn_conv_force_tile: -1 automatic, 0 always 128x128, 1 256x256 wherever it can run;
+ * drn_conv_last_tile: the kernel the last drn_conv3d_igemm call launched (0 / 1). */
+void drn_conv_force_tile(int tile);
+int drn_conv_last_tile(void);
 
 /* ---- CosmosCausalGroupNorm(1 group, per frame) [+ SiLU]: y = [silu](bf16((x-mean)*rstd*gamma + beta)).
  * workspace: drn_groupnorm_workspace_bytes(frames) bytes of device scratch. */

@@ -82,6 +82,88 @@ def test_conv3d_strided_downsample_convs(pkg, gpu):
     assert rel_l2(got2, ref2) < 3e-3
 
 
+CONVS256 = [  # Cin, Cout, k, stride, pad, T, H, W, t_off, residual
+    (64, 256, (1, 3, 3), (1, 1, 1), 1, 2, 20, 24, None, True),       # 960 positions: 3.75 tiles (ragged last tile), 9 taps
+    (128, 256, (3, 1, 1), (1, 1, 1), 0, 5, 16, 16, None, False),     # causal clamp: frames 0 / 1 read frame 0 for kt < 2
+    (64, 512, (1, 1, 1), (1, 1, 1), 0, 3, 16, 20, None, True),       # one K step: prologue only
+    (192, 256, (1, 3, 3), (1, 2, 2), 0, 2, 33, 41, None, False),     # strided, 3 channel slices per tap, 27 K steps (odd)
+    (64, 256, (3, 1, 1), (2, 1, 1), 0, 9, 12, 16, 2, False),         # temporal stride 2 with t_off
+    (256, 256, (3, 3, 3), (1, 1, 1), 1, 3, 10, 12, None, True),      # all three tap axes, 108 K steps
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,T,H,W,t_off,with_res", CONVS256)
+def test_conv256_streamed_kernel_equals_128_kernel(pkg, gpu, Cin, Cout, k, stride, pad, T, H, W, t_off, with_res):
+    """csrc/conv256s.hip (the streamed 256 x 256 tile, gathered A rows) against the 128 x 128 kernel on the same launch:
+    bit-identical (same K order per output element), and against torch's conv3d; the zero halo stays untouched; the residual
+    is also given IN PLACE (output aliases it), as the tokenizer's residual blocks do."""
+    V = pkg.native_vae
+    lib = pkg.native.load_library()
+    x = rnd((Cin, T, H, W), seed=21)
+    w = rnd((Cout, Cin) + k, 1.0 / (Cin * k[0] * k[1] * k[2]) ** 0.5, seed=22)
+    b = rnd((Cout,), 0.1, seed=23)
+    kw = {}
+    if stride[1] == 2:
+        Ho, Wo = (H - k[1]) // 2 + 1, (W - k[2]) // 2 + 1
+        kw["out_dims"] = (T, Ho, Wo)
+    else:
+        Ho, Wo = H, W
+    To = T if stride[0] == 1 else (T + (t_off if t_off is not None else 0) - k[0]) // stride[0] + 1
+    if t_off is not None:
+        kw["t_off"] = t_off
+    res = rnd((Cout, To, Ho, Wo), seed=24) if with_res else None
+    xc, wc, bc = to_cl(pkg, x, gpu), repack(w, gpu), b.to(gpu)
+    outs = {}
+    for tile in (0, 1):
+        lib.drn_conv_force_tile(tile)
+        try:
+            r = to_cl(pkg, res, gpu) if with_res else None
+            y = V.conv3d(xc, wc, bc, Cout, k, stride, pad, residual=r, **kw)
+            assert lib.drn_conv_last_tile() == tile
+            outs[tile] = y
+            if with_res and tile == 1:
+                y2 = V.conv3d(xc, wc, bc, Cout, k, stride, pad, residual=r, out=r, **kw)      # in place
+                assert y2 is r and torch.equal(y2.t, y.t)
+        finally:
+            lib.drn_conv_force_tile(-1)
+    assert (outs[0].T, outs[0].H, outs[0].W) == (To, Ho, Wo)
+    assert torch.equal(outs[0].t, outs[1].t)                                                   # incl. the zero halo
+    xf = x.float()[None]
+    if stride[1] == 2:
+        xf = F.pad(xf, (0, 1, 0, 1, 0, 0))[..., : 2 * (Ho - 1) + k[1], : 2 * (Wo - 1) + k[2]]
+    if t_off is not None:
+        xf = torch.cat([xf[:, :, :1]] * t_off + [xf], 2)
+        ref = F.conv3d(xf, w.float(), b.float(), stride=stride)[0]
+    else:
+        ref = VO.causal_conv3d(xf, w.float(), b.float(), stride, pad)[0]
+    ref = ref.to(BF)
+    if with_res:
+        ref = ref + res
+    got = from_cl(outs[1])
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref.float()) < 3e-3
+
+
+def test_conv256_kernel_is_the_automatic_choice_for_big_convolutions(pkg, gpu):
+    """>= 192 tiles of 256 positions x 256 channels -> the streamed kernel without forcing; small launches stay on 128 x 128."""
+    V = pkg.native_vae
+    lib = pkg.native.load_library()
+    x = rnd((64, 4, 96, 128), seed=31)                  # 49 152 positions = 192 tiles at N = 256
+    w, b = rnd((256, 64, 1, 3, 3), 0.04, seed=32), rnd((256,), 0.1, seed=33)
+    xc, wc, bc = to_cl(pkg, x, gpu), repack(w, gpu), b.to(gpu)
+    y = V.conv3d(xc, wc, bc, 256, (1, 3, 3), (1, 1, 1), 1)
+    assert lib.drn_conv_last_tile() == 1
+    lib.drn_conv_force_tile(0)
+    try:
+        y0 = V.conv3d(xc, wc, bc, 256, (1, 3, 3), (1, 1, 1), 1)
+    finally:
+        lib.drn_conv_force_tile(-1)
+    assert torch.equal(y.t, y0.t)
+    small = to_cl(pkg, rnd((64, 1, 16, 16), seed=34), gpu)
+    V.conv3d(small, wc, bc, 256, (1, 3, 3), (1, 1, 1), 1)
+    assert lib.drn_conv_last_tile() == 0
+
+
 def test_dense_gemm_softmax_transpose(pkg, gpu):
     V = pkg.native_vae
     q, k, v = rnd((100, 128), seed=10).to(gpu), rnd((100, 128), seed=11).to(gpu), rnd((100, 128), seed=12).to(gpu)
