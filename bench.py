@@ -392,6 +392,15 @@ def main():
             roofline = {"bound": "hbm", "kernel": "gemm_bf16_kernel (split-K)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
                         "note": "weight bytes of the executed linears / whole step time (no per-launch events at this size)"}
+            if S >= 1024:
+                # config 2 (S = 1024 / 2048): 256+ FLOP per weight byte x 4-8 -> the MFMA roofline; still no
+                # per-launch events (a pair costs ~35 us, 3 % of a 24 ms step): executed FLOPs over the whole step
+                tf = fl_exec / (ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": "whole DiT step (GEMM tile kernels + attention_fwd_kernel)",
+                            "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "note": "executed FLOPs / whole step time (no per-launch events at this size): a lower bound on "
+                                    "the MFMA kernels' own rate"}
         out = {
             "metric": "denoising_steps_per_sec", "value": round(steps_s, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
