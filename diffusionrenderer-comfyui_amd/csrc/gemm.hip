@@ -425,8 +425,32 @@ extern "C" int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int spl
 // how many K splits keep the CUs busy for an [M, N, K] product (1 = none): at most half of the 512 workgroup slots filled by
 // 128^2 tiles, at most 512 workgroups after the split and at least 16 K steps left per split.  Callers with B clips stacked
 // along the rows pass ONE clip's rows (the split changes the summation order: it must not depend on the batch)
+// Since round 2 the slices of a product whose 256 x 256 tiles x splits fill at least 3/4 of the CUs with >= 16 K steps each run
+// on the streamed kernel (gemm256s.hip; one workgroup per CU, the A slice read once per 256 output columns instead of once per
+// 128): QKV (48 tiles x 4), MLP-up (64 x 4), MLP-down (16 x 16).  DRN_SPLITK256=0 switches that off (A/B runs).
+static int splitk256_choice(int64_t M, int64_t N, int64_t K) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("DRN_SPLITK256");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!mode || M % 256 != 0 || N % 256 != 0 || K % BK != 0 || M > 1024) return 0;
+    const int64_t tiles = (M / 256) * (N / 256);
+    int best = 0;
+    for (int s = 2; s <= 16; s *= 2)
+        if (tiles * s <= 256 && (K / BK) % s == 0 && K / s >= 1024) best = s;
+    return (best && tiles * best >= 192) ? best : 0;
+}
+
+int drn_gemm256s_partial(const void* A, const void* W, float* partial, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                         int splits, void* stream);
+
 extern "C" int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
     if (N % BN != 0 || K % BK != 0 || M <= 0) return 1;
+    if (g_force_tile < 0) {
+        const int s256 = splitk256_choice(M, N, K);
+        if (s256) return s256;
+    }
     if (pick_gemm_tile(M, N) != 0) return 1;
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
     int best = 1;
@@ -450,8 +474,16 @@ extern "C" int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
     DRN_CHECK_ARG(tiles < 65536);
     hipStream_t st = (hipStream_t)stream;
-    gemm_bf16_kernel<DRN_EPI_NONE><<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st>>>(
-        (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, nullptr, nullptr, 0, 1, (float*)workspace);
+    // which kernel computes the slices is a function of ONE clip's rows and the split count the caller got from
+    // drn_gemm_splitk_choice for those rows (batch-invariant results)
+    const int64_t Mb = (rows_per_batch > 0 && rows_per_batch < M && M % rows_per_batch == 0) ? rows_per_batch : M;
+    if (g_force_tile < 0 && M % 256 == 0 && splitk256_choice(Mb, N, K) == splits) {
+        const int rc = drn_gemm256s_partial(A, W, (float*)workspace, M, N, K, lda, ldw, splits, stream);
+        if (rc != DRN_OK) return rc;
+    } else {
+        gemm_bf16_kernel<DRN_EPI_NONE><<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st>>>(
+            (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, nullptr, nullptr, 0, 1, (float*)workspace);
+    }
     int64_t blocks = (M * (N / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
 #define EARGS (const float*)workspace, splits, (bf16_t*)C, M, N, ldc, (const bf16_t*)gate, (const bf16_t*)residual, ldr, rows_per_batch

@@ -54,6 +54,8 @@
 #endif
 #include "gemm256s_core.h"
 
+#define EPI_PARTIAL 3      // internal: split-K slice (blockIdx.y = slice), fp32 tile to the workspace, no epilogue
+
 // epilogue (as gemm256.hip): column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores (16 per lane)
 template <int EPI>
 static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf16_t* C, int64_t M, int64_t N, int64_t ldc,
@@ -68,6 +70,26 @@ static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(acc[i][mt][j][nt]));
+        return;
+    }
+    if (EPI == EPI_PARTIAL) {
+        // split-K slice: the fp32 tile as it is, [split][M][N] (gemm_splitk_epilogue_kernel sums the slices and applies the
+        // epilogue); a lane owns 4 consecutive columns of a row: 16-byte stores
+        float* part = reinterpret_cast<float*>(C);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + fr;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + fq * 4;
+                        if (n < N) *reinterpret_cast<f32x4_t*>(part + m * ldc + n) = acc[i][mt][j][nt];
+                    }
+            }
         return;
     }
     const int64_t c_tile_off = (n0 >> cbc) * cbs + (n0 & ((1ll << cbc) - 1)) - n0;
@@ -149,6 +171,13 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
                                                           int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
                                                           const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
                                                           int abc, int64_t abs_, int cbc, int64_t cbs) {
+    if (EPI == EPI_PARTIAL) {
+        // slice blockIdx.y of gridDim.y: K / gridDim.y columns of A and W (plain layouts), its own fp32 slab of the workspace
+        K /= gridDim.y;
+        A += (int64_t)blockIdx.y * K;
+        W += (int64_t)blockIdx.y * K;
+        C = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(C) + (int64_t)blockIdx.y * M * ldc);
+    }
     THREAD_SETUP();
     int64_t m0, n0;
     tile_of(blockIdx.x, nwg, tiles_m, tiles_n, GROUP, m0, n0);
@@ -299,6 +328,31 @@ static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t 
     gemm256s_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
         ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
+    return drn_launch_status();
+}
+
+// split-K slices of the streamed kernel (small M: gemm.hip drn_gemm_bf16_splitk): partial[split][M][N] fp32.
+// Measured at S = 256 (cfg 1): QKV / MLP-up / MLP-down 52 -> 43 us per launch (48 x 4, 64 x 4, 16 x 16 workgroups of 16 K steps),
+// 7.39 -> 6.97 ms per step.  A workgroup takes in 1 MB in those 43 us = 24 GB/s per CU against ~80 GB/s in the big GEMMs: the
+// weights come cold from HBM and only ~1.25 K steps (80 KB per CU, 15-20 MB chip-wide) are in flight.  Tried: the weights
+// stored K-step-major ([K/64][N][64]: every half-tile one contiguous 16 KiB run instead of 128 runs of 128 B at an 8 KiB
+// stride) - bit-identical, NOT faster (48.5 vs 50.7 us QKV incl. the reduce): DRAM page locality is not the limit, bytes in
+// flight are.  A deeper W ring needs a different LDS budget (A 2 x 32 KiB + W 3 x 32 KiB = the whole 160 KiB).
+int drn_gemm256s_partial(const void* A, const void* W, float* partial, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                         int splits, void* stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI_PARTIAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int64_t tiles = ((M + TB - 1) / TB) * ((N + TB - 1) / TB);
+    if (tiles >= 65536 || splits < 1 || splits > 64 || (K / BK) % splits != 0 || M >= (1ll << 31)) return DRN_EINVAL;
+    static const int64_t plain[4] = {62, 0, 62, 0};
+    gemm256s_kernel<EPI_PARTIAL><<<dim3((unsigned)tiles, (unsigned)splits), dim3(512), 2 * STAGE_BYTES, (hipStream_t)stream>>>(
+        (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)partial, M, N, K, lda, ldw, /*ldc=*/N, nullptr, nullptr, 0, M, 4,
+        (int)plain[0], plain[1], (int)plain[2], plain[3]);
     return drn_launch_status();
 }
 

@@ -487,7 +487,10 @@ def test_gemm_blocked_layouts(pkg, gpu, tile):
 
 
 @pytest.mark.parametrize("M,N,K,epi,splits", [(256, 4096, 4096, 0, 4), (256, 4096, 16384, 2, 8), (200, 512, 2048, 1, 2),
-                                              (512, 1024, 1024, 2, None), (77, 256, 4096, 1, 4)])
+                                              (512, 1024, 1024, 2, None), (77, 256, 4096, 1, 4),
+                                              # the cfg-1 linears whose slices run on the streamed 256 x 256 kernel (automatic)
+                                              (256, 12288, 4096, 0, None), (256, 16384, 4096, 1, None), (256, 4096, 16384, 2, None),
+                                              (512, 12288, 2048, 2, None)])
 def test_gemm_splitk_small_m(pkg, gpu, M, N, K, epi, splits):
     """Few tokens (cfg 1): K split over several workgroups per tile, fp32 partials summed by the epilogue kernel."""
     a, w = rnd((M, K), gpu, seed=95), rnd((N, K), gpu, K ** -0.5, seed=96)
@@ -510,10 +513,40 @@ def test_gemm_splitk_small_m(pkg, gpu, M, N, K, epi, splits):
 
 def test_gemm_splitk_choice(pkg):
     f = pkg.native.load_library().drn_gemm_splitk_choice
-    assert f(256, 4096, 4096) == 4 and f(256, 4096, 16384) == 8      # out-proj / MLP-down at S = 256
-    assert f(256, 12288, 4096) == 2 and f(256, 16384, 4096) == 2     # QKV / MLP-up
+    assert f(256, 4096, 4096) == 4                                   # out-proj at S = 256: 128^2 tiles (16 x 4 of 256^2 = 64 WGs only)
+    assert f(256, 4096, 16384) == 16                                 # MLP-down: 16 tiles of 256^2 x 16 slices of 16 K steps
+    assert f(256, 12288, 4096) == 4 and f(256, 16384, 4096) == 4     # QKV / MLP-up: 48 / 64 tiles of 256^2 x 4 slices
+    lib = pkg.native.load_library()
+    lib.drn_gemm_force_tile(0)
+    try:                                                             # (the 128^2 kernel's own rule)
+        assert f(256, 4096, 16384) == 8 and f(256, 12288, 4096) == 2 and f(256, 16384, 4096) == 2
+    finally:
+        lib.drn_gemm_force_tile(-1)
     assert f(18432, 4096, 4096) == 1 and f(2048, 4096, 4096) == 1    # enough tiles already
     assert f(256, 256, 256) == 1                                     # K too short to split
+
+
+def test_gemm_splitk_256_batch_invariant_and_close_to_128_path(pkg, gpu):
+    """Two clips of 256 tokens stacked along the rows == each clip alone, bit for bit (slice count and kernel come from one
+    clip's rows), on the streamed-kernel split-K path; and that path agrees with the 128 x 128 split-K path to fp32-summation
+    noise (different slice boundaries: not bit-identical)."""
+    lib = pkg.native.load_library()
+    N, K = 12288, 4096
+    a, w = rnd((512, K), gpu, seed=150), rnd((N, K), gpu, K ** -0.5, seed=151)
+    x, gate = rnd((512, N), gpu, seed=152), rnd((2, N), gpu, 0.5, seed=153)
+    both = x.clone()
+    pkg.native.gemm(a, w, out=both, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=both, rows_per_batch=256)
+    for b in range(2):
+        one = x[b * 256:(b + 1) * 256].clone()
+        pkg.native.gemm(a[b * 256:(b + 1) * 256], w, out=one, epilogue=pkg.native.EPI_GATE_RES, gate=gate[b:b + 1], residual=one)
+        assert torch.equal(one, both[b * 256:(b + 1) * 256])
+    lib.drn_gemm_force_tile(0)
+    try:
+        old = x.clone()
+        pkg.native.gemm(a, w, out=old, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=old, rows_per_batch=256)
+    finally:
+        lib.drn_gemm_force_tile(-1)
+    assert (old != both).float().mean() < 0.02 and (old.float() - both.float()).abs().max() <= 2 * 2.0 ** -7 * both.float().abs().max()
 
 
 def test_gemm144_identity_and_choice(pkg, gpu):
