@@ -270,6 +270,37 @@ def test_tokenizer_encode_decode_match_oracle(pkg, gpu, T, H, W):
     assert e_hip <= 1.5 * e_ref + 1e-3
 
 
+def test_tokenizer_full_size_clip_causality_and_determinism(pkg, gpu):
+    """BASELINE configs 3-5 size (57 f x 576 x 1024; the CPU oracle would take hours here): size-independent properties of the
+    causal tokenizer.  Latent frame t depends on pixel frames <= 8t only and pixel frame 8t-7..8t on latent frames <= t, per-frame
+    GroupNorm / spatial attention, causal temporal attention - so a prefix of the clip must encode / decode to the SAME BITS as
+    the prefix of the full result (the big launches run conv256s.hip, the prefix ones partly the 128 x 128 kernel: bit-identical
+    kernels), T = 1 is the image path, and two runs agree bit for bit."""
+    sw = pkg.synthetic_weights
+    _, vae = _tok(pkg, gpu)
+    T, H, W = 57, 576, 1024
+    x = sw.synth_tensor("vae.full", (1, 3, T, H, W), torch.float32, device=gpu).to(BF)
+    z = vae.encode(x)
+    assert z.shape == (1, 16, 8, H // 8, W // 8) and torch.isfinite(z.float()).all()
+    assert torch.equal(vae.encode(x), z)
+    for frames in (1, 17):
+        zp = vae.encode(x[:, :, :frames].contiguous())
+        lf = vae.get_latent_num_frames(frames)
+        same = (zp == z[:, :, :lf]).float().mean().item()
+        print(f"encode prefix {frames} f: {same:.6f} of the latent identical to the full clip's first {lf} frame(s)")
+        assert torch.equal(zp, z[:, :, :lf])
+    y = vae.decode(z)
+    assert y.shape == (1, 3, T, H, W) and torch.isfinite(y.float()).all()
+    for lf in (1, 3):
+        yp = vae.decode(z[:, :, :lf].contiguous())
+        pf = vae.get_pixel_num_frames(lf)
+        same = (yp == y[:, :, :pf]).float().mean().item()
+        print(f"decode prefix {lf} latent frame(s): {same:.6f} of the pixels identical to the full clip's first {pf} frame(s)")
+        assert torch.equal(yp, y[:, :, :pf])
+    # the round trip of a random-init tokenizer is not an identity, but it is a bounded map of a bounded clip
+    assert y.float().abs().max() < 1e4
+
+
 def test_tokenizer_rejects_bad_inputs(pkg, gpu):
     _, vae = _tok(pkg, gpu)
     with pytest.raises(ValueError):
