@@ -164,6 +164,45 @@ def test_forward_node_end_to_end(pkg, gpu):
         node.run_forward_pass(p2, g["depth"], g["normal"], g["roughness"], g["metallic"], g["base_color"], env, env_format="ball")
 
 
+def test_forward_pass_full_size_cfg5(pkg, gpu):
+    """BASELINE config 5 at size: forward renderer, 57 f x 576 x 1024, the full 28-block in_ch-153 network (random-init), the
+    HIP tokenizer (8 condition encodes + the decode), 2 Euler steps through the node.  No CPU oracle exists at this size and the
+    reference cannot run the pass as committed: what is asserted is the boundary contract (shape, dtype, k/255
+    levels in [0, 1]) and that the whole pass - env-map conditions, encodes, sampler with device RNG, decode, uint8 - is
+    reproducible bit for bit from its seed."""
+    sw = pkg.synthetic_weights
+    cfgm = pkg.diffusion_renderer_config
+    T, H, W = 57, 576, 1024
+    cfg = cfgm.get_forward_renderer_config(H, W, T)
+    cfg["model_type"] = "forward"
+    net = dict(cfg["net"])
+    model = pkg.model_diffusion_renderer.CleanDiffusionRendererModel(cfg, device=gpu)
+    model.load_state_dict(sw.synth_state_dict(net, BF, device=gpu), strict=True)
+    vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=gpu), device=gpu)
+    p = pkg.diffusion_renderer_pipeline.CleanDiffusionRendererPipeline(
+        "/nonexistent", "x.pt", model_type=None, vae_instance=vae, model_instance={"forward": model}, guidance=0.0, num_steps=2,
+        height=H, width=W, num_video_frames=T)
+    p.device = gpu
+    node = pkg.NODE_CLASS_MAPPINGS["Cosmos1ForwardRenderer"]()
+    gen = torch.Generator().manual_seed(77)
+    base = torch.rand((1, T, H, W, 3), generator=gen)
+    g = {k: base.roll(i * 37, dims=3) for i, k in enumerate(("depth", "normal", "roughness", "metallic", "base_color"))}
+    env = torch.rand((1, 64, 128, 3), generator=gen) * 4.0
+    outs = []
+    for _ in range(2):
+        (out,) = node.run_forward_pass(p, g["depth"], g["normal"], g["roughness"], g["metallic"], g["base_color"], env,
+                                       guidance=0.0, seed=11, env_format="proj", env_brightness=1.0, env_flip_horizontal=False,
+                                       env_rotation=90.0)
+        outs.append(out)
+    out = outs[0]
+    assert out.shape == (1, T, H, W, 3) and out.dtype == torch.float32
+    assert torch.isfinite(out).all() and 0.0 <= out.min() and out.max() <= 1.0
+    lv = out[0, ::8, ::16, ::16] * 255.0
+    assert torch.equal(lv, lv.round())                                   # k / 255 levels (the uint8 post-process)
+    assert out.std() > 0.01                                              # not a constant image
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_pipeline_error_behaviour(pkg, gpu):
     """Errors at the boundary: no usable key, a clip batch > 1 (the reference cannot run it either), a pass-flag count
     that does not match the context indices."""
