@@ -39,6 +39,9 @@
 // What that says about the one-workgroup-per-tile kernel: launch + cold prologue between tiles cost it nothing measurable
 // (the next workgroup's prologue already overlaps the previous one's store drain); non-temporal C stores (G256S_NT): +-0.5 %.
 //
+// (c) `nt` (aux = 2) or `sc0` (aux = 1) cache-policy bits on the W or A LDS-DMA loads: 0.5-5 % SLOWER on every shape - both
+// operands are re-read from L2 / the Infinity Cache by the other tiles of the band (MI355X_MICROARCH.md 'nt-weights' says the same).
+//
 // Tile, LDS layout (2 stages x [A0 A1 W0 W1] x 16 KiB, 128-B rows, chunk ^ ((row>>1)&7), swizzle on the DMA source address),
 // wave -> quadrant map, blocked operand layouts and the 16-byte epilogue stores are those of gemm256.hip.
 #include <stdlib.h>
