@@ -15,7 +15,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = {"gemm": ("gemm256s_kernel", "gemm256p_kernel", "gemm256_kernel", "gemm144_kernel", "gemm_bf16_kernel"), "attention": ("attention_fwd_kernel", "attention_combine_kernel"),
-            "conv": ("conv_igemm_kernel",)}
+            "conv": ("conv_igemm_kernel", "conv256s_kernel")}
 
 
 def fold(path, counter):
