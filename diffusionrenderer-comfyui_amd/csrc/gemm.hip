@@ -237,6 +237,10 @@ int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64
 // in its persistent form where that applies (gemm256s.hip), 4 = the streamed kernel with one workgroup per tile (= automatic).
 static int g_force_tile = -1;
 extern "C" void drn_gemm_force_tile(int tile) { g_force_tile = tile; }
+static int tall_choice(int64_t M, int64_t N, int64_t K);          // few-token kernel (gemm_tall.hip), defined with the split-K rules
+int drn_gemm_tall_dispatch(const void* A, const void* W, void* C, float* partial, int64_t M, int64_t N, int64_t K, int64_t lda,
+                           int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr,
+                           int64_t rpb, int splits, void* stream);
 
 static int pick_gemm_tile(int64_t M, int64_t N, double* cost_out = nullptr) {
     static int mode256 = -1, mode144 = -1;
@@ -358,6 +362,9 @@ static int gemm_impl(const void* A, const void* W, void* C, int64_t M, int64_t N
     // accumulation order of an output element, so both are chosen from ONE clip's rows - a clip then gets the same bits
     // whatever it is batched with (the reference steps its G-buffer passes / CFG halves one clip at a time, nodes.py:187-213).
     const bool batched = rows_per_batch > 0 && rows_per_batch < M && M % rows_per_batch == 0 && blk[0] == 62 && blk[2] == 62;
+    if (blk[0] == 62 && blk[2] == 62 && M % 256 == 0 && lda >= K && tall_choice(batched ? rows_per_batch : M, N, K) == 1)
+        return drn_gemm_tall_dispatch(A, W, C, nullptr, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr,
+                                      rows_per_batch > 0 ? rows_per_batch : M, 1, stream);
     if (!batched) {
         if (epilogue == DRN_EPI_GATE_RES && rows_per_batch < M) {
             // ragged batches (the last one shorter): one launch with the tile of the whole problem, gates by row / rows_per_batch
@@ -428,6 +435,29 @@ extern "C" int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int spl
 // Since round 2 the slices of a product whose 256 x 256 tiles x splits fill at least 3/4 of the CUs with >= 16 K steps each run
 // on the streamed kernel (gemm256s.hip; one workgroup per CU, the A slice read once per 256 output columns instead of once per
 // 128): QKV (48 tiles x 4), MLP-up (64 x 4), MLP-down (16 x 16).  DRN_SPLITK256=0 switches that off (A/B runs).
+// gemm_tall.hip: one clip of 256 tokens - a workgroup owns all 256 rows x 64 columns over the whole K (no slices where N / 64
+// workgroups fill the chip: QKV 192, MLP-up 256), or over a K slice (out-proj, MLP-down: 64 tiles x 4).  Returns the slice
+// count (1 = unsplit, fused epilogue), 0 = not this kernel.  DRN_GEMM_TALL=0 switches it off (A/B runs).
+int drn_gemm_tall_dispatch(const void* A, const void* W, void* C, float* partial, int64_t M, int64_t N, int64_t K, int64_t lda,
+                           int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr,
+                           int64_t rpb, int splits, void* stream);
+static int tall_choice(int64_t M, int64_t N, int64_t K) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("DRN_GEMM_TALL");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!mode || g_force_tile >= 0 || M != 256 || N % 64 != 0 || K % BK != 0) return 0;
+    const int64_t tiles = N / 64;
+    if (tiles >= 192) return 1;
+    // K slices only while a slice stays short (out-proj: 64 tiles x 4 slices of 16 K steps, 18 + 5 us against 21 + 9 on the
+    // 128^2 path); with 64 K steps per slice every workgroup takes in a quarter of the A panel per slice and the 256^2 slices
+    // win (MLP-down: 58 + 5 us here against 43 + 9)
+    for (int s = 2; s <= 8; s *= 2)
+        if (tiles * s >= 192 && tiles * s <= 256 && (K / BK) % s == 0 && K / s >= 1024 && K / s <= 2048) return s;
+    return 0;
+}
+
 static int splitk256_choice(int64_t M, int64_t N, int64_t K) {
     static int mode = -1;
     if (mode < 0) {
@@ -443,11 +473,15 @@ static int splitk256_choice(int64_t M, int64_t N, int64_t K) {
 }
 
 int drn_gemm256s_partial(const void* A, const void* W, float* partial, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                         int splits, void* stream);
+                         int splits, void* stream, bool wring_ok);
 
 extern "C" int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
     if (N % BN != 0 || K % BK != 0 || M <= 0) return 1;
-    if (g_force_tile < 0) {
+    {
+        const int st = tall_choice(M, N, K);
+        if (st) return st;
+    }
+    if (g_force_tile < 0 || g_force_tile == 4) {           // (4: the same rule, slices on the 2 + 2 stage kernel - tests, A/B)
         const int s256 = splitk256_choice(M, N, K);
         if (s256) return s256;
     }
@@ -477,8 +511,12 @@ extern "C" int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64
     // which kernel computes the slices is a function of ONE clip's rows and the split count the caller got from
     // drn_gemm_splitk_choice for those rows (batch-invariant results)
     const int64_t Mb = (rows_per_batch > 0 && rows_per_batch < M && M % rows_per_batch == 0) ? rows_per_batch : M;
-    if (g_force_tile < 0 && M % 256 == 0 && splitk256_choice(Mb, N, K) == splits) {
-        const int rc = drn_gemm256s_partial(A, W, (float*)workspace, M, N, K, lda, ldw, splits, stream);
+    if (M % 256 == 0 && tall_choice(Mb, N, K) == splits) {
+        const int rc = drn_gemm_tall_dispatch(A, W, C, (float*)workspace, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr,
+                                              rows_per_batch, splits, stream);
+        if (rc != DRN_OK) return rc;
+    } else if ((g_force_tile < 0 || g_force_tile == 4) && M % 256 == 0 && splitk256_choice(Mb, N, K) == splits) {
+        const int rc = drn_gemm256s_partial(A, W, (float*)workspace, M, N, K, lda, ldw, splits, stream, g_force_tile != 4);
         if (rc != DRN_OK) return rc;
     } else {
         gemm_bf16_kernel<DRN_EPI_NONE><<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st>>>(

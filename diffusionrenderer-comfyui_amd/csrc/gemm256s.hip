@@ -199,6 +199,85 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
     store_tile<EPI>(acc, C, M, N, ldc, gate, R, ldr, rpb, cbc, cbs, m0, n0, wr, wc, fr, fq);
 }
 
+// ---- weight-streaming form of the split-K slice kernel (few tokens: the weights come cold from HBM, once).
+// With 2 + 2 stages the DMA of a W half-tile is ~1.25 K steps ahead of its first read: 40 KB of W per CU in flight, which at an
+// HBM round trip under load of ~3 us is 24 GB/s per CU - the slices ran latency-bound (43 us for 16 K steps).  The A slice of a
+// few-token product is shared by every workgroup of its K slice and comes from L2; only W needs depth.  So the whole 160 KiB
+// of LDS becomes A: 2 stages x 32 KiB (as before) + W: 3 stages x 32 KiB, and W is requested THREE steps ahead:
+//     group 1: DMA W0(k+3)   group 2: DMA A0(k+2)   group 3: DMA W1(k+3)   group 4: DMA A1(k+2)
+// In-order vmcnt arithmetic (calls of 2 pieces each, queue per step Q(k) = [W0(k+3) A0(k+2) W1(k+3) A1(k+2)]):
+//     after group 1 needs A1(k)   = last of Q(k-2):   Q(k-1) + 1 call  younger = 10 pieces
+//     after group 2 needs W0(k+1) = first of Q(k-2):  3 + 4 + 2 calls  younger = 18
+//     after group 3 needs A0(k+1) = second of Q(k-1): 2 + 3 calls      younger = 10
+//     after group 4 needs W1(k+1) = third of Q(k-2):  1 + 4 + 4 calls  younger = 18
+// The prologue issues W0(0) W1(0), then the virtual steps Q(-2) = [W0(1) A0(0) W1(1) A1(0)] and Q(-1) = [W0(2) A0(1) W1(2)
+// A1(1)], so that the counts hold from step 0 on.  Same MFMA order per output element as gemm256s_kernel<EPI_PARTIAL>:
+// bit-identical slices.
+#undef A_OFF
+#undef W_OFF
+#define A_OFF(S, I) ((S) * 2 * HALF_BYTES + (I) * HALF_BYTES)                       // 2 stages x [A0 A1]
+#define W_OFF(S, J) (4 * HALF_BYTES + (S) * 2 * HALF_BYTES + (J) * HALF_BYTES)      // 3 stages x [W0 W1]
+#define WS_LDS_BYTES (10 * HALF_BYTES)                                              // 160 KiB
+__global__ __launch_bounds__(512, 2) void gemm256w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                          float* __restrict__ partial, int64_t M, int64_t N, int64_t K,
+                                                          int64_t lda, int64_t ldw, int GROUP) {
+    const int abc = 62, cbc = 62;
+    const int64_t abs_ = 0, cbs = 0;
+    K /= gridDim.y;
+    A += (int64_t)blockIdx.y * K;
+    W += (int64_t)blockIdx.y * K;
+    float* part = partial + (int64_t)blockIdx.y * M * N;
+    THREAD_SETUP();
+    int64_t m0, n0;
+    tile_of(blockIdx.x, nwg, tiles_m, tiles_n, GROUP, m0, n0);
+    SET_SRC(m0, n0);
+    ZERO_ACC();
+#define KCL(k) min((int)(k), nk - 1)
+    // ---- prologue (see above)
+    DMA(H_W0, 0, 0); DMA(H_W1, 0, 0);
+    DMA(H_W0, KCL(1), 1); DMA(H_A0, 0, 0); DMA(H_W1, KCL(1), 1); DMA(H_A1, 0, 0);
+    DMA(H_W0, KCL(2), 2); DMA(H_A0, KCL(1), 1); DMA(H_W1, KCL(2), 2); DMA(H_A1, KCL(1), 1);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // W0(0), W1(0), W0(1), A0(0) have landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wx[nt][ks] = LD_W(0, 0, nt, ks);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[mt][ks] = LD_A(0, 0, mt, ks);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    FENCE();
+    __builtin_amdgcn_s_barrier();                                      // every wave holds W0(0) / A0(0): their regions are free
+    FENCE();
+    // ---- K loop: the A stage (k % 2) and the roles of the two W fragment buffers are literals of a body unrolled by two; the W
+    //      stage (k % 3) is a scalar that walks 0 1 2 (a body unrolled by six with early exits made hipcc merge six fragment
+    //      histories at the loop exit: 1100 spilled registers)
+    int sw = 0;
+#define WSTEP(KT, SA, WA, WB)                                                                                         \
+    do {                                                                                                              \
+        const int swn_ = sw == 2 ? 0 : sw + 1;                                                                        \
+        KSTEP2(SA, (SA) ^ 1, sw, swn_, WA, WB, KCL((KT) + 2), KCL((KT) + 3), 10, 18, 10, 18);                         \
+        sw = swn_;                                                                                                    \
+    } while (0)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        WSTEP(kt, 0, wx, wy);
+        WSTEP(kt + 1, 1, wy, wx);
+    }
+    if (kt < nk) WSTEP(kt, 0, wx, wy);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the re-requests past the last K step
+    store_tile<EPI_PARTIAL>(acc, reinterpret_cast<bf16_t*>(part), M, N, /*ldc=*/N, nullptr, nullptr, 0, M, cbc, cbs, m0, n0, wr, wc,
+                            fr, fq);
+}
+#undef WSTEP
+#undef KCL
+#undef A_OFF
+#undef W_OFF
+#define A_OFF(S, I) ((S) * STAGE_BYTES + (I) * HALF_BYTES)
+#define W_OFF(S, J) ((S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES)
+
 // persistent form: see the header.  Launcher guarantees M % 256 == 0, N % 256 == 0 (every lane stores: STORES_PER_TILE holds),
 // nk even and >= 4, gridDim.x <= number of tiles.
 template <int EPI>
@@ -342,7 +421,7 @@ static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t 
 // stride) - bit-identical, NOT faster (48.5 vs 50.7 us QKV incl. the reduce): DRAM page locality is not the limit, bytes in
 // flight are.  A deeper W ring needs a different LDS budget (A 2 x 32 KiB + W 3 x 32 KiB = the whole 160 KiB).
 int drn_gemm256s_partial(const void* A, const void* W, float* partial, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                         int splits, void* stream) {
+                         int splits, void* stream, bool wring_ok) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI_PARTIAL>),
@@ -352,6 +431,21 @@ int drn_gemm256s_partial(const void* A, const void* W, float* partial, int64_t M
     }
     const int64_t tiles = ((M + TB - 1) / TB) * ((N + TB - 1) / TB);
     if (tiles >= 65536 || splits < 1 || splits > 64 || (K / BK) % splits != 0 || M >= (1ll << 31)) return DRN_EINVAL;
+    static int wring = -1;
+    if (wring < 0) {
+        const char* e = getenv("DRN_SPLITK_WRING");        // 0: the 2 + 2 stage kernel (A/B runs)
+        wring = (e && e[0] == '0') ? 0 : 1;
+        if (wring && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            wring = 0;                                      // (a device that does not grant 160 KiB per workgroup)
+        }
+    }
+    if (wring && wring_ok && K / splits / BK >= 3) {
+        gemm256w_kernel<<<dim3((unsigned)tiles, (unsigned)splits), dim3(512), WS_LDS_BYTES, (hipStream_t)stream>>>(
+            (const bf16_t*)A, (const bf16_t*)W, partial, M, N, K, lda, ldw, 4);
+        return drn_launch_status();
+    }
     static const int64_t plain[4] = {62, 0, 62, 0};
     gemm256s_kernel<EPI_PARTIAL><<<dim3((unsigned)tiles, (unsigned)splits), dim3(512), 2 * STAGE_BYTES, (hipStream_t)stream>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)partial, M, N, K, lda, ldw, /*ldc=*/N, nullptr, nullptr, 0, M, 4,

@@ -49,20 +49,25 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
             }                                                                                                          \
     } while (0)
 
+// LDS regions.  Default: 2 stages x [A0 A1 W0 W1] x 16 KiB.  A kernel may redefine A_OFF / W_OFF before its body (gemm256s.hip's
+// weight-streaming kernel keeps 2 A stages and 3 W stages: the cold operand gets the deeper ring).
+#define A_OFF(S, I) ((S) * STAGE_BYTES + (I) * HALF_BYTES)
+#define W_OFF(S, J) ((S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES)
+#define H_OFF(S, H) ((H) < 2 ? A_OFF(S, (H) & 1) : W_OFF(S, ((H) - 2) & 1))
 // blocked operand layouts (drn_gemm_bf16_blocked), see gemm256.hip
 #define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
 // half-tile H of K step KD (of the tile gsrc points at) into stage S
 #define DMA(H, KD, S)                                                                                                  \
     do {                                                                                                               \
         const int kt_ = (int)(KD);                                                                                     \
-        char* dst_ = smem + (S) * STAGE_BYTES + (H) * HALF_BYTES + dma_off;                                            \
+        char* dst_ = smem + H_OFF(S, H) + dma_off;                                                                     \
         const int64_t ko_ = (H) < 2 ? A_KOFF(kt_) : (int64_t)kt_ * BK;                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][0] + ko_), (lptr_t)dst_, 16, 0, 0);                          \
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][1] + ko_), (lptr_t)(dst_ + 1024), 16, 0, 0);                 \
     } while (0)
 
-#define LD_A(S, I, MT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + (S) * STAGE_BYTES + (I) * HALF_BYTES + ((KS) ? (offa ^ 64) : offa) + (MT) * 2048))
-#define LD_W(S, J, NT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + (S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES + ((KS) ? (offw ^ 64) : offw) + (NT) * 2048))
+#define LD_A(S, I, MT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + A_OFF(S, I) + ((KS) ? (offa ^ 64) : offa) + (MT) * 2048))
+#define LD_W(S, J, NT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + W_OFF(S, J) + ((KS) ? (offw ^ 64) : offw) + (NT) * 2048))
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MM(I, MT, J, NT, KS, WF)                                                                                    \
@@ -84,52 +89,56 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
         PREFETCH;                                                                                                   \
         FENCE();                                                                                                    \
     } while (0)
-// K step in stage S (a literal) with W0 of this step in WA: groups 1..4; the DMA of the step two ahead (k index KD of the tile
-// gsrc points at) goes into the regions they free.  On exit af = A0 and WB = W0 of the next step.  V1..V4: the hand-over waits.
-#define KSTEP(S, WA, WB, KD, V1, V2, V3, V4)                                                                        \
+// K step with its A half-tiles in A stage SA and its W half-tiles in W stage SW (literals; SAN / SWN = the stages of the NEXT
+// step), W0 of this step in WA: groups 1..4; the DMA of a later step (k indices KDA / KDW of the tile gsrc points at) goes into
+// the regions they free.  On exit af = A0 and WB = W0 of the next step.  V1..V4: the hand-over waits.
+#define KSTEP2(SA, SAN, SW, SWN, WA, WB, KDA, KDW, V1, V2, V3, V4)                                                  \
     do {                                                                                                            \
         /* group 1 (A0,W0): request W1 -> WB; DMA W0(+2) */                                                         \
-        SLOT(0, 0, 0, 0, WA, WB[0][0] = LD_W(S, 1, 0, 0));                                                          \
-        SLOT(0, 0, 1, 0, WA, WB[1][0] = LD_W(S, 1, 1, 0));                                                          \
-        SLOT(0, 0, 2, 0, WA, WB[0][1] = LD_W(S, 1, 0, 1));                                                          \
-        SLOT(0, 0, 3, 0, WA, WB[1][1] = LD_W(S, 1, 1, 1));                                                          \
-        DMA(H_W0, KD, S);                                                                                           \
+        SLOT(0, 0, 0, 0, WA, WB[0][0] = LD_W(SW, 1, 0, 0));                                                          \
+        SLOT(0, 0, 1, 0, WA, WB[1][0] = LD_W(SW, 1, 1, 0));                                                          \
+        SLOT(0, 0, 2, 0, WA, WB[0][1] = LD_W(SW, 1, 0, 1));                                                          \
+        SLOT(0, 0, 3, 0, WA, WB[1][1] = LD_W(SW, 1, 1, 1));                                                          \
+        DMA(H_W0, KDW, SW);                                                                                           \
         FENCE();                                                                                                    \
         SLOT(0, 0, 0, 1, WA, (void)0); SLOT(0, 0, 1, 1, WA, (void)0); SLOT(0, 0, 2, 1, WA, (void)0); SLOT(0, 0, 3, 1, WA, (void)0); \
         HANDOVER(V1);                    /* A1 of this step has landed */                                           \
         /* group 2 (A0,W1): request A1 -> af as its A0 entries die; DMA A0(+2) */                                   \
-        SLOT(0, 1, 0, 0, WB, af[0][0] = LD_A(S, 1, 0, 0));                                                          \
-        SLOT(0, 1, 1, 0, WB, af[1][0] = LD_A(S, 1, 1, 0));                                                          \
-        SLOT(0, 1, 2, 0, WB, af[2][0] = LD_A(S, 1, 2, 0));                                                          \
-        SLOT(0, 1, 3, 0, WB, af[3][0] = LD_A(S, 1, 3, 0));                                                          \
-        DMA(H_A0, KD, S);                                                                                           \
+        SLOT(0, 1, 0, 0, WB, af[0][0] = LD_A(SA, 1, 0, 0));                                                          \
+        SLOT(0, 1, 1, 0, WB, af[1][0] = LD_A(SA, 1, 1, 0));                                                          \
+        SLOT(0, 1, 2, 0, WB, af[2][0] = LD_A(SA, 1, 2, 0));                                                          \
+        SLOT(0, 1, 3, 0, WB, af[3][0] = LD_A(SA, 1, 3, 0));                                                          \
+        DMA(H_A0, KDA, SA);                                                                                           \
         FENCE();                                                                                                    \
-        SLOT(0, 1, 0, 1, WB, af[0][1] = LD_A(S, 1, 0, 1));                                                          \
-        SLOT(0, 1, 1, 1, WB, af[1][1] = LD_A(S, 1, 1, 1));                                                          \
-        SLOT(0, 1, 2, 1, WB, af[2][1] = LD_A(S, 1, 2, 1));                                                          \
-        SLOT(0, 1, 3, 1, WB, af[3][1] = LD_A(S, 1, 3, 1));                                                          \
+        SLOT(0, 1, 0, 1, WB, af[0][1] = LD_A(SA, 1, 0, 1));                                                          \
+        SLOT(0, 1, 1, 1, WB, af[1][1] = LD_A(SA, 1, 1, 1));                                                          \
+        SLOT(0, 1, 2, 1, WB, af[2][1] = LD_A(SA, 1, 2, 1));                                                          \
+        SLOT(0, 1, 3, 1, WB, af[3][1] = LD_A(SA, 1, 3, 1));                                                          \
         HANDOVER(V2);                    /* W0 of the next step has landed */                                       \
         /* group 3 (A1,W1): request W0(+1) -> WB as it dies; DMA W1(+2) */                                          \
         SLOT(1, 1, 0, 0, WB, (void)0); SLOT(1, 1, 1, 0, WB, (void)0); SLOT(1, 1, 2, 0, WB, (void)0);                \
-        SLOT(1, 1, 3, 0, WB, (WB[0][0] = LD_W((S) ^ 1, 0, 0, 0), WB[1][0] = LD_W((S) ^ 1, 0, 1, 0)));               \
-        DMA(H_W1, KD, S);                                                                                           \
+        SLOT(1, 1, 3, 0, WB, (WB[0][0] = LD_W(SWN, 0, 0, 0), WB[1][0] = LD_W(SWN, 0, 1, 0)));               \
+        DMA(H_W1, KDW, SW);                                                                                           \
         FENCE();                                                                                                    \
         SLOT(1, 1, 0, 1, WB, (void)0); SLOT(1, 1, 1, 1, WB, (void)0); SLOT(1, 1, 2, 1, WB, (void)0);                \
-        SLOT(1, 1, 3, 1, WB, (WB[0][1] = LD_W((S) ^ 1, 0, 0, 1), WB[1][1] = LD_W((S) ^ 1, 0, 1, 1)));               \
+        SLOT(1, 1, 3, 1, WB, (WB[0][1] = LD_W(SWN, 0, 0, 1), WB[1][1] = LD_W(SWN, 0, 1, 1)));               \
         HANDOVER(V3);                    /* A0 of the next step has landed */                                       \
         /* group 4 (A1,W0): request A0(+1) -> af as its A1 entries die; DMA A1(+2) */                               \
-        SLOT(1, 0, 0, 0, WA, af[0][0] = LD_A((S) ^ 1, 0, 0, 0));                                                    \
-        SLOT(1, 0, 1, 0, WA, af[1][0] = LD_A((S) ^ 1, 0, 1, 0));                                                    \
-        SLOT(1, 0, 2, 0, WA, af[2][0] = LD_A((S) ^ 1, 0, 2, 0));                                                    \
-        SLOT(1, 0, 3, 0, WA, af[3][0] = LD_A((S) ^ 1, 0, 3, 0));                                                    \
-        DMA(H_A1, KD, S);                                                                                           \
+        SLOT(1, 0, 0, 0, WA, af[0][0] = LD_A(SAN, 0, 0, 0));                                                    \
+        SLOT(1, 0, 1, 0, WA, af[1][0] = LD_A(SAN, 0, 1, 0));                                                    \
+        SLOT(1, 0, 2, 0, WA, af[2][0] = LD_A(SAN, 0, 2, 0));                                                    \
+        SLOT(1, 0, 3, 0, WA, af[3][0] = LD_A(SAN, 0, 3, 0));                                                    \
+        DMA(H_A1, KDA, SA);                                                                                           \
         FENCE();                                                                                                    \
-        SLOT(1, 0, 0, 1, WA, af[0][1] = LD_A((S) ^ 1, 0, 0, 1));                                                    \
-        SLOT(1, 0, 1, 1, WA, af[1][1] = LD_A((S) ^ 1, 0, 1, 1));                                                    \
-        SLOT(1, 0, 2, 1, WA, af[2][1] = LD_A((S) ^ 1, 0, 2, 1));                                                    \
-        SLOT(1, 0, 3, 1, WA, af[3][1] = LD_A((S) ^ 1, 0, 3, 1));                                                    \
+        SLOT(1, 0, 0, 1, WA, af[0][1] = LD_A(SAN, 0, 0, 1));                                                    \
+        SLOT(1, 0, 1, 1, WA, af[1][1] = LD_A(SAN, 0, 1, 1));                                                    \
+        SLOT(1, 0, 2, 1, WA, af[2][1] = LD_A(SAN, 0, 2, 1));                                                    \
+        SLOT(1, 0, 3, 1, WA, af[3][1] = LD_A(SAN, 0, 3, 1));                                                    \
         HANDOVER(V4);                    /* W1 of the next step has landed */                                       \
     } while (0)
+
+// the two-stage form: A and W of a step share stage S, the step two ahead is requested
+#define KSTEP(S, WA, WB, KD, V1, V2, V3, V4) KSTEP2(S, (S) ^ 1, S, (S) ^ 1, WA, WB, KD, KD, V1, V2, V3, V4)
 
 // (hook for a DMA macro that keeps a cursor instead of using the K index it is given: conv256s.hip)
 #ifndef BETWEEN_PROLOGUE_STEPS

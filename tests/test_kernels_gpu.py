@@ -513,9 +513,11 @@ def test_gemm_splitk_small_m(pkg, gpu, M, N, K, epi, splits):
 
 def test_gemm_splitk_choice(pkg):
     f = pkg.native.load_library().drn_gemm_splitk_choice
-    assert f(256, 4096, 4096) == 4                                   # out-proj at S = 256: 128^2 tiles (16 x 4 of 256^2 = 64 WGs only)
-    assert f(256, 4096, 16384) == 16                                 # MLP-down: 16 tiles of 256^2 x 16 slices of 16 K steps
-    assert f(256, 12288, 4096) == 4 and f(256, 16384, 4096) == 4     # QKV / MLP-up: 48 / 64 tiles of 256^2 x 4 slices
+    # one clip of 256 tokens: gemm_tall.hip - 256 x 64 tiles over the whole K where N / 64 workgroups fill the chip ...
+    assert f(256, 12288, 4096) == 1 and f(256, 16384, 4096) == 1     # QKV / MLP-up: 192 / 256 workgroups, no slices
+    assert f(256, 4096, 4096) == 4                                   # ... out-proj: 64 tiles x 4 slices of 16 K steps
+    assert f(256, 4096, 16384) == 16                                 # MLP-down: 16 tiles of 256^2 x 16 slices (weight-ring kernel)
+    assert f(512, 12288, 2048) == 2 and f(1024, 4096, 16384) == 4    # 2-4 clips' rows: 256^2 tiles x slices (weight-ring kernel)
     lib = pkg.native.load_library()
     lib.drn_gemm_force_tile(0)
     try:                                                             # (the 128^2 kernel's own rule)
@@ -526,10 +528,77 @@ def test_gemm_splitk_choice(pkg):
     assert f(256, 256, 256) == 1                                     # K too short to split
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(512, 12288, 2048, 2), (1024, 4096, 4096, 0), (512, 12288, 4352, 1), (1024, 4096, 16384, 2),
+                                       (512, 12288, 2560, 0)])
+def test_gemm_splitk_weight_ring_kernel_equals_two_stage_kernel(pkg, gpu, M, N, K, epi):
+    """The few-token slices on the weight-streaming kernel (A 2 stages + W 3 stages of LDS, W requested three K steps ahead,
+    hand-over waits vmcnt 10 / 18 / 10 / 18) against the same slices on the 2 + 2 stage kernel (force_tile 4): the MFMA order per
+    output element is the same, so the results must be bit-identical; 16, 34, 64 and 20 K steps per slice (even, and not a
+    multiple of the W ring's period).  (One clip of 256 rows takes gemm_tall.hip instead: 512 / 1024 rows here.)"""
+    lib = pkg.native.load_library()
+    a, w = rnd((M, K), gpu, seed=160), rnd((N, K), gpu, K ** -0.5, seed=161)
+    x, gate = rnd((M, N), gpu, seed=162), rnd((1, N), gpu, 0.5, seed=163)
+    assert lib.drn_gemm_splitk_choice(M, N, K) > 1
+    outs = {}
+    for tile in (-1, 4):
+        lib.drn_gemm_force_tile(tile)
+        try:
+            if epi == 2:
+                out = x.clone()
+                pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out)
+            else:
+                out = pkg.native.gemm(a, w, epilogue=epi)
+            outs[tile] = out
+        finally:
+            lib.drn_gemm_force_tile(-1)
+    assert torch.equal(outs[-1], outs[4])
+
+
+@pytest.mark.parametrize("N,K,epi", [(12288, 4096, 0), (16384, 4096, 1), (12288, 4096, 2), (4096, 4096, 2), (4096, 16384, 2),
+                                     (12288, 192, 1), (16384, 64, 0)])
+def test_gemm_tall_kernel(pkg, gpu, N, K, epi):
+    """gemm_tall.hip (one clip of 256 rows; 256 x 64 tiles, 4-stage LDS ring, W and A three K steps ahead): unsplit it is
+    bit-identical to the 128 x 128 kernel run unsplit (same K order per output element) for all three epilogues, in place for
+    the gated residual; with K slices (N = 4096) within the usual bound of the fp32 product.  64, 256, 3 and 1 K steps."""
+    lib = pkg.native.load_library()
+    M = 256
+    a, w = rnd((M, K), gpu, seed=170), rnd((N, K), gpu, K ** -0.5, seed=171)
+    x, gate = rnd((M, N), gpu, seed=172), rnd((1, N), gpu, 0.5, seed=173)
+    splits = lib.drn_gemm_splitk_choice(M, N, K)
+    assert splits == (1 if N >= 12288 else (4 if K == 4096 else 16))
+
+    def run(**kw):
+        if epi == 2:
+            out = x.clone()
+            pkg.native.gemm(a, w, out=out, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=out, **kw)
+            return out
+        return pkg.native.gemm(a, w, epilogue=epi, **kw)
+
+    got = run()
+    lib.drn_gemm_force_tile(0)
+    try:
+        plain = run(splitk=1)
+    finally:
+        lib.drn_gemm_force_tile(-1)
+    if splits == 1:
+        assert torch.equal(got, plain)
+    lin = (a.float() @ w.float().t()).to(BF)
+    mag = None
+    if epi == 0:
+        ref = lin
+    elif epi == 1:
+        ref = F.gelu(lin.cpu()).to(gpu)
+    else:
+        ref = x + gate * lin
+        mag = torch.maximum(x.abs(), (gate * lin).abs())
+    ok, msg = ulp_diff_ok(got, ref, max_ulp=2, frac_exact=0.97, mag=mag)
+    assert ok, msg
+
+
 def test_gemm_splitk_256_batch_invariant_and_close_to_128_path(pkg, gpu):
     """Two clips of 256 tokens stacked along the rows == each clip alone, bit for bit (slice count and kernel come from one
-    clip's rows), on the streamed-kernel split-K path; and that path agrees with the 128 x 128 split-K path to fp32-summation
-    noise (different slice boundaries: not bit-identical)."""
+    clip's rows: gemm_tall.hip, unsplit here); and that path agrees with the 128 x 128 split-K path to fp32-summation noise
+    (different slice boundaries: not bit-identical)."""
     lib = pkg.native.load_library()
     N, K = 12288, 4096
     a, w = rnd((512, K), gpu, seed=150), rnd((N, K), gpu, K ** -0.5, seed=151)

@@ -7,5 +7,5 @@ rc=$?
 tail -8 gpurun_out/chk_tests.log
 if [ $rc -ne 0 ]; then exit $rc; fi
 for v in 0 1; do
-  DRN_SPLITK256=$v timeout -k 10 250 python bench.py --config cfg1 --steps 16 --warmup 4 --no-cpu-baseline --no-tokenizer --no-cfg 2>/dev/null | cut -c1-200 || exit 1
+  DRN_GEMM_TALL=$v timeout -k 10 250 python bench.py --config cfg1 --steps 16 --warmup 4 --no-cpu-baseline --no-tokenizer --no-cfg 2>/dev/null | cut -c1-200 || exit 1
 done
