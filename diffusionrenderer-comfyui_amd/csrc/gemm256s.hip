@@ -41,6 +41,10 @@
 //
 // (c) `nt` (aux = 2) or `sc0` (aux = 1) cache-policy bits on the W or A LDS-DMA loads: 0.5-5 % SLOWER on every shape - both
 // operands are re-read from L2 / the Infinity Cache by the other tiles of the band (MI355X_MICROARCH.md 'nt-weights' says the same).
+// (d) an L2 'touch' - one global_load_dword per wave and K step over the 128-byte lines that the DMA will ask for 3-6 K steps
+// later (hand-over waits 12 / 12 / 11 / 11), meant to turn the ~19 % of operand bytes that miss the XCD's L2 into hits: 15-27 %
+// SLOWER on every shape.  A 64-line load costs the CU's vector-memory path more than the two 1 KiB DMA pieces it stands beside;
+// that path (one DMA piece per ~37 cycles per CU) is what the operand side of this kernel is bound by.
 //
 // Tile, LDS layout (2 stages x [A0 A1 W0 W1] x 16 KiB, 128-B rows, chunk ^ ((row>>1)&7), swizzle on the DMA source address),
 // wave -> quadrant map, blocked operand layouts and the 16-byte epilogue stores are those of gemm256.hip.
