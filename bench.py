@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -124,7 +125,7 @@ CONFIGS = {   # BASELINE.json configs that fit one node: (frames, height, width,
     "cfg2a": (8, 512, 512, 5, 1),      # the reference's own arithmetic for 8 frames: latent (1,64,64), S = 1024
     "cfg3": (57, 576, 1024, 3, 1),     # the headline: full Cosmos clip, S = 18 432
 }
-PROBE_FAILED_RC = 75          # a rank's RCCL all-to-all probe failed: the launcher starts a FRESH run with the all-gather exchange
+PROBE_FAILED_RC = 75          # exit code of a rank whose RCCL all-to-all probe failed (torchrun relays it as 1: see PROBE_MARKER)
 
 
 def free_port() -> int:
@@ -133,30 +134,63 @@ def free_port() -> int:
         return sk.getsockname()[1]
 
 
+PROBE_MARKER = "[bench] PROBE_FAILED all_to_all_single"      # printed on stdout by a rank whose all-to-all probe failed
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` (how the driver calls it): start N ranks as a CHILD torch.distributed.run, relay rank 0's JSON
-    line and the exit code.  Runs before anything touches the GPU; never an exec (gpurun forbids exec after GPU init and a
-    child keeps this process free to retry).  If a rank reports that the all-to-all exchange cannot run on this RCCL build
-    (exit code PROBE_FAILED_RC), ONE fresh run is started with DRN_SP_EXCHANGE=gather - a communicator is not reused after a
-    failed collective."""
+    line and the exit code.  Runs before anything touches the GPU; never an exec (gpurun forbids exec after GPU init).
+
+    ONE situation starts a second run: a rank printed PROBE_MARKER, i.e. its all-to-all probe (tried before anything is timed)
+    raised - this RCCL build cannot run the head <-> token exchange.  torch.distributed.run folds a rank's exit code into 1, so
+    the marker line, not the code, identifies it.  A communicator is not reused after a failed collective, hence a FRESH run with
+    DRN_SP_EXCHANGE=gather, and the relayed JSON line says so (`exchange_fallback`, `first_attempt_rc`).  Every other failure
+    (a GPU fault, an assert, a kill) is relayed as it is, once, with the child's exit code; a child that outlives
+    DRN_BENCH_TIMEOUT_S (default 3000) is terminated (SIGTERM, then SIGKILL) and the launcher exits 124."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("DRN_BENCH_TIMEOUT_S", "3000"))
+    first_rc = None
     for attempt in (0, 1):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-        line = None
-        for ln in proc.stdout.splitlines():
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            stdout, _ = proc.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            # torch.distributed.run puts every rank in a session of its own, so a group kill of the launcher's child would
+            # orphan them: SIGTERM first (its handler terminates the ranks it started), SIGKILL only if it does not return
+            proc.terminate()
+            try:
+                proc.communicate(timeout=30)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)        # exactly the group this launcher started
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+            print(f"[bench] {n}-rank run exceeded {limit:.0f} s: killed", file=sys.stderr, flush=True)
+            return 124
+        line, probe_failed = None, False
+        for ln in stdout.splitlines():
             t = ln.strip()
             if t.startswith("{") and '"metric"' in t:
                 line = t
             elif t:
+                probe_failed = probe_failed or PROBE_MARKER in t
                 print(t, file=sys.stderr, flush=True)
         if line is not None and proc.returncode == 0:
+            if attempt == 1:
+                rec = json.loads(line)
+                rec["exchange_fallback"] = True
+                rec["first_attempt_rc"] = first_rc
+                rec["retried_exchange"] = "gather"
+                line = json.dumps(rec)
             print(line, flush=True)
             return 0
-        if attempt == 0 and env.get("DRN_SP_EXCHANGE", "auto") != "gather":
-            print(f"[bench] {n}-rank run ended with rc {proc.returncode}; one fresh run with DRN_SP_EXCHANGE=gather", file=sys.stderr, flush=True)
+        if attempt == 0 and probe_failed and env.get("DRN_SP_EXCHANGE", "auto") != "gather":
+            first_rc = proc.returncode
+            print(f"[bench] all-to-all probe failed (rc {proc.returncode}); one fresh run with DRN_SP_EXCHANGE=gather", file=sys.stderr, flush=True)
             env["DRN_SP_EXCHANGE"] = "gather"
             continue
         return proc.returncode or 1
@@ -167,6 +201,20 @@ def dry_run(args, world, rank):
     """Launcher rehearsal on CPU (tests/test_bench_launcher.py): gloo rendezvous at 127.0.0.1, a barrier, a MAX all-reduce and
     rank 0's JSON line - everything bench.py does around the timed region except the GPU work itself."""
     import torch.distributed as dist
+    # test hook (tests/test_bench_launcher.py): DRN_DRYRUN_FAIL="<rank>:<rc>" makes that rank fail like a crashed child,
+    # "<rank>:probe" like a rank whose all-to-all probe raised (only while the all-to-all exchange is selected, as the real probe)
+    hook = os.environ.get("DRN_DRYRUN_FAIL", "")
+    if hook:
+        hr, what = hook.split(":")
+        if int(hr) == rank:
+            if what == "probe":
+                if os.environ.get("DRN_SP_EXCHANGE", "auto") != "gather":
+                    print(PROBE_MARKER + " (dry-run hook)", flush=True)
+                    os._exit(PROBE_FAILED_RC)
+            elif what == "hang":
+                time.sleep(600)
+            else:
+                os._exit(int(what))
     if world > 1 or "WORLD_SIZE" in os.environ:
         dist.init_process_group("gloo")
         dist.barrier()
@@ -194,6 +242,10 @@ def main():
     ap.add_argument("--no-tokenizer", action="store_true", help="skip the (untimed) tokenizer encode/decode leg")
     ap.add_argument("--no-cfg", action="store_true", help="skip the secondary guidance-2.0 (cond + uncond) figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU (gloo): no GPU work")
+    ap.add_argument("--no-pass", action="store_true", help="skip the wall-clocked generate_video pass (pass_measured)")
+    ap.add_argument("--pass-steps", type=int, default=35, help="denoising steps of the measured pass (BASELINE: 35)")
+    ap.add_argument("--node-pass", action="store_true",
+                    help="also wall-clock the inverse node's call: 5 G-buffer passes stepped as one batch (nodes.py:187-213)")
     args = ap.parse_args()
     cf, ch, cw, cs, cwu = CONFIGS[args.config]
     args.frames = cf if args.frames is None else args.frames
@@ -231,6 +283,7 @@ def main():
                 torch.cuda.synchronize()
             except Exception as e:                                       # noqa: BLE001 - any transport error
                 print(f"[bench] rank {rank}: all_to_all_single failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+                print(PROBE_MARKER, flush=True)                # stdout: the launcher retries on this line only
                 os._exit(PROBE_FAILED_RC)
 
     pkg = load_package()
@@ -282,14 +335,14 @@ def main():
     pkg.parallel.set_exchange_timer(xtimer)
     if pg is not None and world == 1:
         pkg.parallel.SINGLE_RANK_COLLECTIVES = True       # 1-rank rehearsal under torchrun: issue the RCCL calls anyway
-    host_enqueue = 0.0
+    host_loop = 0.0
     t0 = time.perf_counter()
     # inside the timed region: the timed steps' AdaLN vectors, batched as generate_samples_from_batch does before its loop
     model.net.prepare_timesteps([float(model.scheduler.timesteps[i]) for i in range(args.warmup, total)])
     for i in range(args.warmup, total):
         h0 = time.perf_counter()
         xt = one_step(i, xt)
-        host_enqueue += time.perf_counter() - h0      # launches are asynchronous: this is the host's share of a step
+        host_loop += time.perf_counter() - h0         # wall time of the host loop: enqueue work + queue back-pressure
     barrier()
     elapsed = time.perf_counter() - t0
     N.set_timer(None)
@@ -299,6 +352,15 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = tmax.item()
     assert torch.isfinite(xt.float()).all(), "non-finite latent"
+    # the host's own cost of a step: ONE step enqueued on an EMPTY queue (nothing to wait for), outside the timed region.  The
+    # loop figure above also contains the time the host spent blocked on the full HIP queue, i.e. mostly GPU time.
+    model.scheduler.set_timesteps(max(total, 2))
+    barrier()
+    h0 = time.perf_counter()
+    _x = one_step(0, xt)
+    host_empty_ms = 1e3 * (time.perf_counter() - h0)
+    barrier()
+    del _x
 
     # ---- secondary figure: the same step at the pipeline's default guidance 2.0 = cond + uncond forwards, which the
     #      sampler runs as ONE batch of two clips; one warm-up + two timed steps, outside the headline's timed region
@@ -323,7 +385,7 @@ def main():
 
     # ---- tokenizer leg (rank 0, outside the timed region): one encode + one decode of the full clip, for frames/s and the
     #      conv kernel's achieved HBM rate.  Random-init CV8x8x8 weights; synthetic RGB clip resident in HBM.
-    tok = None
+    tok, vae = None, None
     if rank == 0 and not args.no_tokenizer:
         try:
             vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=dev), device=dev)
@@ -348,11 +410,55 @@ def main():
                    "conv_tflops": round(cs["flops"] / (cs["ms_total"] * 1e-3) / 1e12, 1),
                    "conv_hbm_gbs_algorithmic": round(cs["bytes"] / (cs["ms_total"] * 1e-3) / 1e9, 1),
                    "hbm_frac": round(cs["bytes"] / (cs["ms_total"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-            del vae, clip, z, rec, u8
+            del clip, z, rec, u8
             torch.cuda.empty_cache()
         except Exception as e:                      # noqa: BLE001 - the headline line must survive a failure of this optional leg
             print(f"[bench] tokenizer leg failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             tok = None
+            vae = None
+
+    # ---- a REAL pass through the drop-in boundary (rank 0, one GPU, outside the headline's timed region): the reference's
+    #      CleanDiffusionRendererPipeline.generate_video (diffusion_renderer_pipeline.py:242-321) on a HOST clip - H2D, tokenizer
+    #      encode, condition assembly, prepare_timesteps, N Euler steps at guidance 0, decode, post-process, D2H - wall-clocked
+    #      from the call to the uint8 array.  frames/s of BASELINE.json's metric = frames / that time.
+    pass_measured, node_measured = None, None
+    if rank == 0 and world == 1 and tok is not None and not args.no_pass and args.blocks == 28:
+        try:
+            pipe = pkg.diffusion_renderer_pipeline.CleanDiffusionRendererPipeline(
+                "/nonexistent", "synthetic.pt", model_type=None, vae_instance=vae, model_instance=model, guidance=0.0,
+                num_steps=args.pass_steps, seed=42)
+            pipe.set_model_type("inverse")
+            rgb = sw.synth_tensor("bench.rgb", (1, 3, args.frames, args.height, args.width), torch.float32)     # host, fp32 (IMAGE)
+            batch = {"rgb": rgb, "video": rgb, "context_index": torch.full((1, 1), 3, dtype=torch.long)}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            u8 = pipe.generate_video(batch, normalize_normal=True, seed=42)
+            dt = time.perf_counter() - t0
+            assert u8.shape == (1, args.frames, args.height, args.width, 3) and u8.dtype.name == "uint8"
+            pass_measured = {"seconds": round(dt, 3), "frames_per_sec": round(args.frames / dt, 3), "steps": args.pass_steps,
+                             "what": "generate_video(host fp32 clip) -> uint8 ndarray: H2D + encode + conditions + "
+                                     f"{args.pass_steps} steps (guidance 0) + decode + post-process + D2H, wall clock"}
+            del u8
+            if args.node_pass:
+                node = pkg.nodes.Cosmos1InverseRenderer()
+                image = ((rgb + 1.0) * 0.5).permute(0, 2, 3, 4, 1).contiguous()        # (B,T,H,W,C) in [0,1], as ComfyUI hands it over
+                pipe._h2d_cache = {}
+                model._enc_cache.clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                outs = node.run_inverse_pass(pipe, image, guidance=0.0, seed=42)
+                dt5 = time.perf_counter() - t0
+                assert len(outs) == 5 and tuple(outs[0].shape) == (args.frames, args.height, args.width, 3)
+                node_measured = {"seconds": round(dt5, 3), "passes": 5, "frames_per_sec_per_pass": round(5 * args.frames / dt5, 3),
+                                 "steps": args.pass_steps,
+                                 "what": "Cosmos1InverseRenderer.run_inverse_pass: 5 G-buffer passes stepped as one batch, one "
+                                         "encode, 5 decodes, uint8 -> float IMAGE tensors on the host"}
+                del outs
+            del pipe, rgb, batch
+        except Exception as e:                      # noqa: BLE001 - optional leg
+            print(f"[bench] measured pass failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+    vae = None
+    torch.cuda.empty_cache()
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -405,7 +511,8 @@ def main():
             "metric": "denoising_steps_per_sec", "value": round(steps_s, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "rccl_ranks": world,
-            "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 2),
+            "host_enqueue_ms_empty_queue": round(host_empty_ms, 2),
+            "host_loop_wall_ms_per_step": round(1e3 * host_loop / args.steps, 2),
             "config": {"workload": f"inverse pass, {args.frames}f x {args.height} x {args.width} clip: EDM Euler step = 1 DiT "
                                    f"forward (D=4096, {args.blocks} blocks, 32 heads) over S={S} tokens, guidance 0",
                        "latent": [16, F_, h, w], "tokens": S, "parallelism": (f"sp{world} (token bands; self-attention exchange: "
@@ -429,6 +536,15 @@ def main():
         if tok is not None:
             out["tokenizer"] = tok
             out["frames_per_sec_35step_pass"] = round(args.frames / ((tok["encode_ms"] + 35 * ms + tok["decode_ms"]) * 1e-3), 3)
+            out["frames_per_sec_35step_pass_note"] = "composed: frames / (encode + 35 x ms_per_step + decode); pass_measured is the wall clock"
+        if pass_measured is not None:
+            out["pass_measured"] = pass_measured
+            if tok is not None:
+                comp = (tok["encode_ms"] + args.pass_steps * ms + tok["decode_ms"]) * 1e-3
+                pass_measured["composed_seconds"] = round(comp, 3)
+                pass_measured["measured_over_composed"] = round(pass_measured["seconds"] / comp, 4)
+        if node_measured is not None:
+            out["node_pass_measured"] = node_measured
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_full(pkg, net, sd_cpu, (F_, h, w), 4) if sd_cpu is not None else cpu_baseline(pkg, S)
         print(json.dumps(out), flush=True)

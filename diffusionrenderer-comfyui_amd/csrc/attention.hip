@@ -49,6 +49,9 @@
 #ifndef ATT_DMA_IN_S
 #define ATT_DMA_IN_S 0
 #endif
+// (pieces requested in S(t) would use the row offsets that M_QK(t) has already clamped for the LAST tile while they still belong
+//  to a full tile: the variant needs its own unclamped offsets before it may be built again)
+static_assert(ATT_DMA_IN_S == 0, "ATT_DMA_IN_S > 0 reads clamped K/V rows for tile nt-2: fix S_REQ's offsets first");
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
@@ -549,6 +552,8 @@ static int attention_launch(const void* q, const void* k, const void* v, void* o
     DRN_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
     DRN_CHECK_ARG(bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 8 == 0);
     DRN_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 15) == 0);
+    // the tile DMA addresses a K / V row as a 32-bit byte offset from the tile's first row (64 rows x ld x 2 B)
+    DRN_CHECK_ARG(ldk > 0 && ldv > 0 && 64 * ldk * 2 < (1ll << 32) && 64 * ldv * 2 < (1ll << 32));
     if (Sq == 0) return DRN_OK;
     int64_t kv_chunk = Sk;
     if (nsplit > 1) {

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         return;
     }
     // ---- epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = 16 j + 4*(lane>>4) + r; column tiles j = 2p / 2p+1 are
-    //      exchanged between lane rows fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 16 B (see gemm256.hip)
+    //      exchanged between lane rows fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 16 B (see gemm256s.hip)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m_raw = m0 + wm * 64 + i * 16 + fr;
@@ -213,15 +213,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const float* 
     }
 }
 
-// gemm256.hip: 256x256x64 ping-pong kernel for the large shapes
-int drn_gemm256_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                         int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                         void* stream, const int64_t* blk);
-
-// gemm256s.hip: the same tile, streamed schedule (tile kernel 3; takes over tile kernel 1's problems unless DRN_GEMM_STREAM=0)
+// gemm256s.hip: 256x256x64 tile, streamed schedule (tile kernel 1; 3 and 4 are accepted as aliases by drn_gemm_force_tile)
 int drn_gemm256s_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                           int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                          void* stream, const int64_t* blk, bool persistent_ok);
+                          void* stream, const int64_t* blk);
 
 // gemm144.hip: 144x256x64 kernel (token bands of sequence parallelism: M = 2304 k)
 int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
@@ -233,8 +228,8 @@ int drn_gemm144_dispatch(const void* A, const void* W, void* C, int64_t M, int64
 // workgroup does 56 % of the work of a 256^2 one at 0.85-1.0x its rate: DRN_GEMM144_COST = 0.64 units (measured: M = 2304
 // -> 0.79 vs 0.97 ms per DiT block; M = 18432 stays on 256^2).
 // Returns 0: 128^2, 1: 256^2, 2: 144x256.   DRN_GEMM256=0 / DRN_GEMM144=0 switch a kernel off, DRN_GEMM144=2 forces it (A/B runs).
-// drn_gemm_force_tile: -1 automatic, 0 / 1 / 2 as above (1 = the first-generation 256^2 kernel), 3 = the streamed 256^2 kernel
-// in its persistent form where that applies (gemm256s.hip), 4 = the streamed kernel with one workgroup per tile (= automatic).
+// drn_gemm_force_tile: -1 automatic, 0 / 1 / 2 as above; 3 = 1 (kept for callers of round 2); 4 = 1 with the split-K slices of
+// the small-M path on the 2 + 2 stage kernel instead of the weight-ring kernel (tests, A/B).
 static int g_force_tile = -1;
 extern "C" void drn_gemm_force_tile(int tile) { g_force_tile = tile; }
 static int tall_choice(int64_t M, int64_t N, int64_t K);          // few-token kernel (gemm_tall.hip), defined with the split-K rules
@@ -276,16 +271,8 @@ static const int64_t kPlain[4] = {62, 0, 62, 0};
 static int gemm_launch_tile(int tile, const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr,
                             int64_t rows_per_batch, void* stream, const int64_t* blk) {
-    static int stream_mode = -1;
-    if (stream_mode < 0) {
-        const char* e = getenv("DRN_GEMM_STREAM");
-        stream_mode = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (tile == 3 || tile == 4 || (tile == 1 && stream_mode == 1 && g_force_tile != 1))
-        return drn_gemm256s_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk,
-                                     g_force_tile == 3);
-    if (tile == 1)
-        return drn_gemm256_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
+    if (tile == 1 || tile == 3 || tile == 4)
+        return drn_gemm256s_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
     if (tile == 2)
         return drn_gemm144_dispatch(A, W, C, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr, rows_per_batch, stream, blk);
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);

@@ -7,10 +7,10 @@
 // One workgroup = 8 waves = 2 groups of 4; every SIMD hosts one wave of each group.  The groups split the K step: group g
 // multiplies the k-substep g (32 of the 64 columns) of the WHOLE 144 x 256 tile, wave (g, wn) owning output columns
 // 64 wn .. 64 wn + 63 -> 9 x 4 accumulator tiles (144 VGPRs), 13 ds_read_b128 per 36 MFMAs.  The two partial sums meet in
-// LDS after the K loop.  As in gemm256.hip the groups run ONE barrier apart and a phase is
+// LDS after the K loop.  As in gemm256s.hip the groups run ONE barrier apart and a phase is
 // {fragment reads + global->LDS DMA} | barrier | {12 MFMAs} | barrier, three phases (48 rows each) per K step.
 // Three LDS stages of 50 KiB (A 144 x 128 B, W 256 x 128 B): the DMA of K step k+2 overwrites the stage read in step k-1;
-// one counted s_waitcnt vmcnt per K step.  XOR-swizzled rows as in gemm256.hip.
+// one counted s_waitcnt vmcnt per K step.  XOR-swizzled rows as in gemm256s.hip.
 #include <stdlib.h>
 #include "drn_common.h"
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
                 acc[mt][(OWN) + h] += *reinterpret_cast<const f32x4_t*>(mine + (mt * 2 + h) * 1024);    \
     } while (0)
     // epilogue of the owned tiles: lane holds C[m][n..n+3] of both; the two column tiles are exchanged between lane rows
-    // fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 8 consecutive outputs, 16 B (see gemm256.hip)
+    // fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 8 consecutive outputs, 16 B (see gemm256s.hip)
 #define STORE_TILES(OWN)                                                                                \
     do {                                                                                                \
         _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                              \

@@ -1,6 +1,6 @@
-// 256x256x64 bf16 GEMM, "streamed" schedule (second generation of gemm256.hip):  C = epi(A[M,K] . W[N,K]^T)
+// 256x256x64 bf16 GEMM, "streamed" schedule:  C = epi(A[M,K] . W[N,K]^T)
 //
-// Measured on the first-generation kernel (tools/kbench.py, QKV shape, MI355X): MFMAs + barriers alone 0.92 ms, its memory
+// Measured on the first-generation kernel of round 1 (a ping-pong of two wave groups, removed in round 3; QKV shape, MI355X): MFMAs + barriers alone 0.92 ms, its memory
 // pipeline alone (DMA + fragment reads + barriers) 0.96 ms, both together 1.50 ms - the fragment reads sit in bursts of 12 / 4 /
 // 8 / 0 ds_read_b128 at the head of a phase, in front of a barrier, and a 12-read burst of four waves (48 KiB) outlasts the
 // partner group's 16 MFMAs.  Here no wave ever stops to load:
@@ -26,18 +26,10 @@
 // with the matrix pipes idle - the `G256S_ABL=8` build) do not coincide: 1.5-10 % SLOWER, monotonically in the stagger -
 // tiles that run in lock step share their A / W panels in the XCD's L2, out of step they do not.
 //
-// Persistent form (gemm256p_kernel; whole 256-tiles, even K/64 >= 4, more tiles than CUs): one workgroup per CU walks the tiles
-// blockIdx.x, +gridDim.x, ... and the DMA stream never stops - the last two K steps of a tile already request K steps 0 and 1 of
-// the workgroup's NEXT tile and the fragment prefetch of the last K step reads them, so a tile starts with no launch, no cold
-// prologue (~2 us of exposed DMA latency per tile before) and its MFMAs run while the previous tile's C stores drain.  The 16
-// stores of the epilogue sit in the in-order vmcnt queue BEHIND the 5 half-tiles requested before them: the first five
-// hand-overs of the new tile wait vmcnt(10 + 16), the sixth (vmcnt(10)) is the first that needs the stores to have been
-// acknowledged.  Same tile order, same summation order per tile: bit-identical to gemm256s_kernel.
-// Measured (tools/kbench.py --tiles 3,4, M = 18432): out-proj +2.6 %, MLP-up / MLP-down +-0.3 %, QKV -3.9 % (13.5 rounds of
-// tiles: the hardware dispatcher hands the last half round to whichever CUs finish first, the static walk makes half the
-// CUs do 14 tiles) - no net gain, so it is NOT the default: drn_gemm_force_tile(3) or DRN_GEMM_PERSISTENT=1 select it.
-// What that says about the one-workgroup-per-tile kernel: launch + cold prologue between tiles cost it nothing measurable
-// (the next workgroup's prologue already overlaps the previous one's store drain); non-temporal C stores (G256S_NT): +-0.5 %.
+// A persistent form (one workgroup per CU walking its tiles, DMA stream crossing the tile boundary) was built and measured in
+// round 2 (out-proj +2.6 %, MLP +-0.3 %, QKV -3.9 %; it also spilled 8 B per lane) and removed in round 3: no net gain.  Launch +
+// cold prologue between tiles cost the one-workgroup-per-tile kernel nothing measurable (the next workgroup's prologue already
+// overlaps the previous one's store drain); non-temporal C stores (G256S_NT): +-0.5 %.
 //
 // (c) `nt` (aux = 2) or `sc0` (aux = 1) cache-policy bits on the W or A LDS-DMA loads: 0.5-5 % SLOWER on every shape - both
 // operands are re-read from L2 / the Infinity Cache by the other tiles of the band (MI355X_MICROARCH.md 'nt-weights' says the same).
@@ -47,7 +39,7 @@
 // that path (one DMA piece per ~37 cycles per CU) is what the operand side of this kernel is bound by.
 //
 // Tile, LDS layout (2 stages x [A0 A1 W0 W1] x 16 KiB, 128-B rows, chunk ^ ((row>>1)&7), swizzle on the DMA source address),
-// wave -> quadrant map, blocked operand layouts and the 16-byte epilogue stores are those of gemm256.hip.
+// wave -> quadrant map and blocked operand layouts: gemm256s_core.h.
 #include <stdlib.h>
 #include "drn_common.h"
 
@@ -63,7 +55,7 @@
 
 #define EPI_PARTIAL 3      // internal: split-K slice (blockIdx.y = slice), fp32 tile to the workspace, no epilogue
 
-// epilogue (as gemm256.hip): column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores (16 per lane)
+// epilogue: column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores (16 per lane)
 template <int EPI>
 static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf16_t* C, int64_t M, int64_t N, int64_t ldc,
                                                   const bf16_t* __restrict__ gate, const bf16_t* R, int64_t ldr, int64_t rpb,
@@ -282,134 +274,25 @@ __global__ __launch_bounds__(512, 2) void gemm256w_kernel(const bf16_t* __restri
 #define A_OFF(S, I) ((S) * STAGE_BYTES + (I) * HALF_BYTES)
 #define W_OFF(S, J) ((S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES)
 
-// persistent form: see the header.  Launcher guarantees M % 256 == 0, N % 256 == 0 (every lane stores: STORES_PER_TILE holds),
-// nk even and >= 4, gridDim.x <= number of tiles.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
-                                                          const bf16_t* R, int64_t ldr, int64_t rpb, int GROUP,
-                                                          int abc, int64_t abs_, int cbc, int64_t cbs) {
-    THREAD_SETUP();
-    (void)gsrc;
-    // DMA addresses: a scalar base per (tile, half-tile, K step) + one 32-bit lane offset per operand and piece (whole tiles:
-    // no row clamp), the `global_load_lds saddr + voffset` form - 4 address registers instead of 16, no 64-bit vector adds
-    uint32_t voffa[2], voffw[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int rl = p * 8 + (lane >> 3);                              // row inside this wave's 16 rows of a half-tile
-        const int c = (lane & 7) ^ ((rl >> 1) & 7);                      // (wave * 16 is a multiple of 16: no part in the swizzle)
-        voffa[p] = (uint32_t)((rl * lda + c * 8) * 2);
-        voffw[p] = (uint32_t)((rl * ldw + c * 8) * 2);
-    }
-#undef DMA
-#define DMA(H, KD, S)                                                                                                  \
-    do {                                                                                                               \
-        const int kt_ = (int)(KD);                                                                                     \
-        char* dst_ = smem + (S) * STAGE_BYTES + (H) * HALF_BYTES + dma_off;                                            \
-        const char* sb_ = (H) < 2 ? sa_tile + (((int64_t)((H) * 128) * lda + A_KOFF(kt_)) << 1)                        \
-                                  : sw_tile + (((int64_t)(((H) - 2) * 128) * ldw + (int64_t)kt_ * BK) << 1);            \
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + ((H) < 2 ? voffa[0] : voffw[0])), (lptr_t)dst_, 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + ((H) < 2 ? voffa[1] : voffw[1])), (lptr_t)(dst_ + 1024), 16, 0, 0); \
-    } while (0)
-#define SET_TILE(M0, N0)                                                                                               \
-    do {                                                                                                               \
-        sa_tile = reinterpret_cast<const char*>(A + ((M0) + wave * 16) * lda);                                         \
-        sw_tile = reinterpret_cast<const char*>(W + ((N0) + wave * 16) * ldw);                                         \
-    } while (0)
-    const char *sa_tile, *sw_tile;
-    int vb = blockIdx.x;
-    int64_t m0, n0;
-    tile_of(vb, nwg, tiles_m, tiles_n, GROUP, m0, n0);
-    SET_TILE(m0, n0);
-    ZERO_ACC();
-    const int k_second = 1;
-    PROLOGUE();
-    KSTEP(0, wx, wy, 2, 10, 10, 10, 10);
-    KSTEP(1, wy, wx, 3, 10, 10, 10, 10);
-    for (;;) {
-        for (int kt = 2; kt < nk - 2; kt += 2) {
-            KSTEP(0, wx, wy, kt + 2, 10, 10, 10, 10);
-            KSTEP(1, wy, wx, kt + 3, 10, 10, 10, 10);
-        }
-        // every request of this tile is out: the DMA stream moves on to the next tile (or re-requests this one's last step)
-        const int vn = vb + (int)gridDim.x;
-        const bool more = vn < nwg;
-        int64_t m1 = m0, n1 = n0;
-        int k0 = nk - 1, k1 = nk - 1;
-        if (more) {
-            tile_of(vn, nwg, tiles_m, tiles_n, GROUP, m1, n1);
-            SET_TILE(m1, n1);
-            k0 = 0;
-            k1 = 1;
-        }
-        KSTEP(0, wx, wy, k0, 10, 10, 10, 10);
-        KSTEP(1, wy, wx, k1, 10, 10, 10, 10);          // its last two hand-overs: W0(0) / A0(0) of the next tile have landed
-        FENCE();
-        store_tile<EPI>(acc, C, M, N, ldc, gate, R, ldr, rpb, cbc, cbs, m0, n0, wr, wc, fr, fq);
-        FENCE();
-        if (!more) break;
-        ZERO_ACC();
-        m0 = m1;
-        n0 = n1;
-        vb = vn;
-        // the fragments of K step 0 are read again here rather than kept across the epilogue (48 registers it needs); the barrier
-        // keeps a wave that runs ahead from re-filling those regions (DMA of K step 2, groups 1 / 2) under a slower wave's reads
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wx[nt][ks] = LD_W(0, 0, nt, ks);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = LD_A(0, 0, mt, ks);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        FENCE();
-        // the stores are younger than the half-tiles the first five hand-overs wait for
-        KSTEP(0, wx, wy, 2, 26, 26, 26, 26);
-        KSTEP(1, wy, wx, 3, 26, 10, 10, 10);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-static_assert(STORES_PER_TILE == 16, "the vmcnt(26) hand-overs above are 10 + STORES_PER_TILE");
-
-static int g_cus = 0;
-
 template <int EPI>
 static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                       int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
-                      const int64_t* blk, bool persistent_ok) {
+                      const int64_t* blk) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const int64_t tiles = ((M + TB - 1) / TB) * ((N + TB - 1) / TB);
     if (tiles >= (1ll << 31) || M >= (1ll << 31)) return DRN_EINVAL;
     if (rpb > M || rpb <= 0) rpb = M;                      // (32-bit row / rows_per_batch arithmetic in the epilogue)
-    static int group = 0, persistent = -1;
+    static int group = 0;
     if (group == 0) {
         const char* e = getenv("DRN_GEMM_GROUP");          // tile-rows per L2 band (A/B experiments)
         group = e ? atoi(e) : 4;
         if (group < 1) group = 4;
-        e = getenv("DRN_GEMM_PERSISTENT");                 // 1: persistent form wherever it applies; default: only when forced
-        persistent = e ? atoi(e) : 0;                      // (drn_gemm_force_tile(3)) - see the header for the measurement
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            g_cus = 0;
-    }
-    const int64_t nk = K / BK;
-    if ((persistent || persistent_ok) && g_cus >= 8 && g_cus % 8 == 0 && tiles > g_cus && M % TB == 0 && N % TB == 0 && nk >= 4 && nk % 2 == 0) {
-        gemm256p_kernel<EPI><<<dim3((unsigned)g_cus), dim3(512), 2 * STAGE_BYTES, st>>>(
-            (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate,
-            (const bf16_t*)residual, ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
-        return drn_launch_status();
     }
     gemm256s_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
@@ -460,12 +343,12 @@ int drn_gemm256s_partial(const void* A, const void* W, float* partial, int64_t M
 // called from gemm.hip (tile kernel 3); arguments already validated there
 int drn_gemm256s_dispatch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                           int64_t ldc, int epilogue, const void* gate, const void* residual, int64_t ldr, int64_t rpb,
-                          void* stream, const int64_t* blk, bool persistent_ok) {
+                          void* stream, const int64_t* blk) {
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case DRN_EPI_NONE: return launch256s<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, persistent_ok);
-        case DRN_EPI_GELU: return launch256s<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, persistent_ok);
-        case DRN_EPI_GATE_RES: return launch256s<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, persistent_ok);
+        case DRN_EPI_NONE: return launch256s<DRN_EPI_NONE>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_GELU: return launch256s<DRN_EPI_GELU>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
+        case DRN_EPI_GATE_RES: return launch256s<DRN_EPI_GATE_RES>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk);
         default: return DRN_EINVAL;
     }
 }

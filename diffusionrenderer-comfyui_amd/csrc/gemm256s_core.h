@@ -54,7 +54,7 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
 #define A_OFF(S, I) ((S) * STAGE_BYTES + (I) * HALF_BYTES)
 #define W_OFF(S, J) ((S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES)
 #define H_OFF(S, H) ((H) < 2 ? A_OFF(S, (H) & 1) : W_OFF(S, ((H) - 2) & 1))
-// blocked operand layouts (drn_gemm_bf16_blocked), see gemm256.hip
+// blocked operand layouts (drn_gemm_bf16_blocked), see gemm256s.hip
 #define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
 // half-tile H of K step KD (of the tile gsrc points at) into stage S
 #define DMA(H, KD, S)                                                                                                  \

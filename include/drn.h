@@ -19,7 +19,8 @@
  *     K|V all-gather; parallel.py) are issued by the host through torch.distributed (backend "nccl" = RCCL over xGMI) on the
  *     tensors the kernels below read and write - drn_gemm_bf16_blocked / drn_permute_021 produce and consume the rank-major
  *     slabs of those exchanges directly.
- *   - drn_attention_bf16: the output base and its row / batch strides must allow 16-byte stores (o % 16 == 0, ldo % 8 == 0).
+ *   - drn_attention_bf16: the output base and its row / batch strides must allow 16-byte stores (o % 16 == 0, ldo % 8 == 0);
+ *     the K / V tile DMA addresses a row as a 32-bit byte offset from its tile's first row: 64 * ldk * 2 and 64 * ldv * 2 < 2^32.
  */
 #ifndef DRN_H
 #define DRN_H

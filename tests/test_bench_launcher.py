@@ -34,8 +34,31 @@ def test_single_rank_does_not_spawn():
     assert rec["n_gpus"] == 1 and rec["steps"] == 4      # cfg1's own step count
 
 
-def test_child_failure_is_relayed():
-    # a rank count that contradicts the environment the child sees: the child exits non-zero, so must the launcher (after its
-    # one retry with the all-gather exchange)
-    p = _run("--gpus", "2", "--dry-run", "--blocks", "not-a-number")
+def test_child_failure_is_relayed_once_without_retry():
+    # rank 1 of the CHILD exits non-zero (not an argparse error of the parent): the launcher relays a failure, prints no JSON line
+    # and does NOT start the all-gather retry - that is reserved for a failed all-to-all probe
+    p = _run("--gpus", "2", "--dry-run", env={"DRN_DRYRUN_FAIL": "1:3"})
     assert p.returncode != 0 and not p.stdout.strip()
+    assert "one fresh run" not in p.stderr and "PROBE_FAILED" not in p.stderr
+
+
+def test_probe_failure_retries_once_with_gather_and_says_so():
+    p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", env={"DRN_DRYRUN_FAIL": "0:probe"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stderr.count("one fresh run with DRN_SP_EXCHANGE=gather") == 1
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["exchange_fallback"] is True and rec["retried_exchange"] == "gather" and rec["first_attempt_rc"] not in (0, None)
+
+
+def test_probe_failure_with_gather_already_selected_is_not_retried():
+    # the hook only fires while the all-to-all exchange is selected, as the real probe: with gather nothing fails
+    p = _run("--gpus", "2", "--dry-run", env={"DRN_DRYRUN_FAIL": "0:probe", "DRN_SP_EXCHANGE": "gather"})
+    assert p.returncode == 0 and "one fresh run" not in p.stderr
+    assert "exchange_fallback" not in json.loads(p.stdout.strip())
+
+
+def test_hung_child_is_killed_at_the_limit():
+    p = _run("--gpus", "2", "--dry-run", env={"DRN_DRYRUN_FAIL": "1:hang", "DRN_BENCH_TIMEOUT_S": "20"})
+    assert p.returncode == 124 and not p.stdout.strip()
