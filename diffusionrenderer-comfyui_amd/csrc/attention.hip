@@ -52,10 +52,28 @@
 // (pieces requested in S(t) would use the row offsets that M_QK(t) has already clamped for the LAST tile while they still belong
 //  to a full tile: the variant needs its own unclamped offsets before it may be built again)
 static_assert(ATT_DMA_IN_S == 0, "ATT_DMA_IN_S > 0 reads clamped K/V rows for tile nt-2: fix S_REQ's offsets first");
+// ATT_PTR 1: the DMA source of a tile is a running scalar pointer advanced once per tile (0: recomputed per piece from the tile
+// index - ~15 scalar instructions of 64-bit multiply per piece in front of the DMA, inside the MFMA stream)
+#ifndef ATT_PTR
+#define ATT_PTR 1
+#endif
+// ATT_TIE 1: a counted LDS wait ties its fragment's registers ("+v": hipcc then pads the following MFMA with an s_nop);
+// 0: the wait is a bare s_waitcnt, its place is held by the sched_barrier fences alone
+#ifndef ATT_TIE
+#define ATT_TIE 1
+#endif
+// ATT_BAR1 1: ONE barrier per tile.  G0 runs [M(t) S(t)] | barrier, G1 runs [S(t-1) M(t)] | barrier: inside an interval the two
+// groups still alternate on the matrix pipe (M beside S, then S beside M) but nothing stops them in the middle; the K / V rings
+// (3 / 4 tiles) are deep enough that a tile's buffer is never re-filled in the interval that reads it.  0: barrier after every segment.
+#ifndef ATT_BAR1
+#define ATT_BAR1 0
+#endif
 #define QROWS 256        // query rows per workgroup
 #define KVT 64           // keys per tile
 #define KBYTES (KVT * 256)
+#ifndef NKB
 #define NKB 3            // K tile buffers
+#endif
 #define NVB 4            // V tile buffers
 #ifndef RESCALE_THR
 #define RESCALE_THR 6.0f   // log2 units
@@ -159,6 +177,12 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
             DMA16(kt_ + kso[(P) >> 1], smem + (KBUF) * KBYTES + dma_off + ((P) >> 1) * 1024); \
         }                                                                                     \
     } while (0)
+    // the same with the tile's K / V base taken from the running pointers kreq_p / vreq_p (tile min(t + 2, nt - 1) during M(t))
+#define DMA_PIECE_P(P, KBUF, VBUF)                                                            \
+    do {                                                                                      \
+        if ((P) & 1) DMA16(vreq_p + vso[(P) >> 1], smem + (NKB + (VBUF)) * KBYTES + dma_off + ((P) >> 1) * 1024); \
+        else DMA16(kreq_p + kso[(P) >> 1], smem + (KBUF) * KBYTES + dma_off + ((P) >> 1) * 1024); \
+    } while (0)
 #define STAGE_TILE(TILE, KBUF, VBUF)                                                          \
     do {                                                                                      \
         DMA_PIECE(0, TILE, KBUF, VBUF); DMA_PIECE(1, TILE, KBUF, VBUF);                       \
@@ -220,8 +244,13 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
                  : "=&v"(DST.lo), "=&v"(DST.hi)                                                                    \
                  : "v"(va[(F) & 3]), "i"((32 * (KT2) + 16 * ((F) >> 2)) * 256), "i"((32 * (KT2) + 16 * ((F) >> 2) + 8) * 256) \
                  : "memory")
+#if ATT_TIE
 #define WAIT_K(N, X) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(X) : "i"(N) : "memory")
 #define WAIT_V(N, X) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(X.lo), "+v"(X.hi) : "i"(N) : "memory")
+#else
+#define WAIT_K(N, X) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory")
+#define WAIT_V(N, X) asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory")
+#endif
 #define JOIN(X) __builtin_shufflevector(X.lo, X.hi, 0, 1, 2, 3, 4, 5, 6, 7)
 #define MFMA(A, B, C) ((ATT_ABL & 4) ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0))
 #define K_STEP(DELTA) do { _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) ka[ks] += (DELTA); } while (0)
@@ -293,7 +322,10 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     DMA_WAIT(0);
     BARRIER();
     if (nt == 3 && last_rows < KVT) CLAMP_LAST_TILE();                // M(0) requests tile 2
-    if (grp == 1) BARRIER();                       // G1 runs one interval behind G0
+    if (!ATT_BAR1 && grp == 1) BARRIER();          // G1 runs one interval behind G0
+    const int64_t ktile_bytes = (int64_t)KVT * ldk * 2, vtile_bytes = (int64_t)KVT * ldv * 2;
+    const char* kreq_p = reinterpret_cast<const char*>(Kb) + (int64_t)min(2, nt - 1) * ktile_bytes;   // tile that M(0) requests
+    const char* vreq_p = reinterpret_cast<const char*>(Vb) + (int64_t)min(2, nt - 1) * vtile_bytes;
 
     bf16x8_t ka_[8], kb_[8];                       // K fragments of key half 0 / 1
     struct vfrag_t { bf16x4_t lo, hi; } va_[8], vb_[8];   // V fragments of key half 0 / 1 (halves as the transposed reads deliver them)
@@ -340,7 +372,10 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
 #define ZERO_S(KT2) do { _Pragma("unroll") for (int r = 0; r < 16; ++r) s[KT2][r] = 0.f; } while (0)
 #define REQ_PIECE_NOW(P, T)                                                                   \
     do {                                                                                      \
-        if (!(ATT_ABL & 16)) DMA_PIECE(P, min((T) + 2, nt - 1), kreq, vreq);                  \
+        if (!(ATT_ABL & 16)) {                                                                \
+            if (ATT_PTR) DMA_PIECE_P(P, kreq, vreq);                                          \
+            else DMA_PIECE(P, min((T) + 2, nt - 1), kreq, vreq);                              \
+        }                                                                                     \
         FENCE();                                                                              \
     } while (0)
     // pieces 0 .. ATT_DMA_IN_S-1 wait for the softmax segment (S_REQ), the others are requested between the MFMA blocks
@@ -368,12 +403,15 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         kreq = kreq == NKB - 1 ? 0 : kreq + 1;                                                \
         vreq = vreq == NVB - 1 ? 0 : vreq + 1;                                                \
         if ((T) + 3 == nt - 1 && last_rows < KVT) CLAMP_LAST_TILE();    /* before M(t+1) requests the last tile */ \
+        if (ATT_PTR && (T) + 3 <= nt - 1) { kreq_p += ktile_bytes; vreq_p += vtile_bytes; }   /* M(t+1) requests tile min(t+3, nt-1) */ \
         FENCE();                                                                              \
         if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);                                          \
         STAMP(0);                        /* M work */                                         \
-        DMA_WAIT(4 - ATT_DMA_IN_S);      /* tile T+1: only this segment's pieces of tile T+2 are younger */ \
-        STAMP(1);                        /* DMA wait */                                       \
-        BARRIER();                                                                            \
+        if (!ATT_BAR1 || grp == 1) {                                                          \
+            DMA_WAIT(4 - ATT_DMA_IN_S);  /* tile T+1: only this segment's pieces of tile T+2 are younger */ \
+            STAMP(1);                    /* DMA wait */                                       \
+            BARRIER();                                                                        \
+        }                                                                                     \
         STAMP(2);                        /* barrier at the end of M */                        \
     } while (0)
     // ---- S(t): softmax only; the first V half of tile t (requested during QK1) is complete at its end
@@ -385,10 +423,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)"                                                   \
                      : "+v"(va_[0].lo), "+v"(va_[0].hi), "+v"(va_[1].lo), "+v"(va_[1].hi), "+v"(va_[2].lo), "+v"(va_[2].hi), \
                        "+v"(va_[3].lo), "+v"(va_[3].hi), "+v"(va_[4].lo), "+v"(va_[4].hi), "+v"(va_[5].lo), "+v"(va_[5].hi), \
-                       "+v"(va_[6].lo), "+v"(va_[6].hi), "+v"(va_[7].lo), "+v"(va_[7].hi) :: "memory"); \
+                       "+v"(va_[6].lo), "+v"(va_[6].hi), "+v"(va_[7].lo), "+v"(va_[7].hi),     \
+                       "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]), "+v"(l_run) :: "memory"); \
+        /* (pb / l_run tied: the softmax is complete HERE - with a conditional barrier behind it hipcc otherwise sinks the exp / \
+           pack half of the softmax into the block after the barrier) */                      \
         _Pragma("unroll") for (int f = 0; f < 8; ++f) vc_[f] = JOIN(va_[f]);                  \
         STAMP(3);                        /* S work */                                         \
-        BARRIER();                                                                            \
+        if (!ATT_BAR1) BARRIER();                                                             \
+        else if (grp == 0) { DMA_WAIT(4); BARRIER(); }   /* (its M(t) requests are a whole segment old: nothing to wait for) */ \
         STAMP(4);                        /* barrier at the end of S */                        \
     } while (0)
 
@@ -436,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_kernel(
     STEP_PV1(0, 0); STEP_PV1(1, 0); STEP_PV1(2, 0); STEP_PV1(3, 0); STEP_PV1(4, 0); STEP_PV1(5, 0); STEP_PV1(6, 0); STEP_PV1(7, 0);
     if (ATT_PRIO) __builtin_amdgcn_s_setprio(0);
     DMA_WAIT(0);                                   // (the clamped re-requests of the last tile: nothing may land after the epilogue took the LDS)
-    if (grp == 0) BARRIER();                       // balance G1's extra barrier
+    if (!ATT_BAR1 && grp == 0) BARRIER();          // balance G1's extra barrier
 #if ATT_DIAG
     {
         unsigned long long dg_r1, dg_c1;

@@ -117,8 +117,18 @@ def main():
                 print(f"    {nm:18s} {x[:, i].median().item() / tiles:8.0f} cycles per tile  ({x[:, i].median().item() / tot * 100:5.1f} %)")
     for name, fn, fl in cases:
         times = [[] for _ in handles]
-        for lib in handles:
+        ref_out = None
+        for i, lib in enumerate(handles):
+            if name.startswith("attention"):
+                o.zero_()
             fn(lib)
+            if name.startswith("attention") and len(handles) > 1:          # variants keep the summation order: same bits expected
+                torch.cuda.synchronize()
+                if ref_out is None:
+                    ref_out = o.clone()
+                else:
+                    print(f"    {os.path.basename(libs[i])}: identical to {os.path.basename(libs[0])}: {torch.equal(o, ref_out)}  "
+                          f"max|diff| {(o.float() - ref_out.float()).abs().max().item():.3e}", flush=True)
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for i, lib in enumerate(handles):
