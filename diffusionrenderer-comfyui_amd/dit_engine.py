@@ -89,6 +89,9 @@ class HipDiT:
         self._ws = {}
         self._graphs = {}
         self.trace = None          # tests: dict filled with per-sub-block activations "block{i}.{j}" -> [S, D]
+        # DRN_PER_LAUNCH=1: one ctypes call per kernel (the path the sharded engine and the traces use) instead of the
+        # drn_dit_forward sequencer - same kernels, same bits (tests compare the two)
+        self._per_launch = os.environ.get("DRN_PER_LAUNCH", "0") == "1"
 
     # ------------------------------------------------------------------ weights
     def _load(self, sd, p):
@@ -150,6 +153,19 @@ class HipDiT:
         self.w_cao = torch.stack(ca_o, 0).contiguous() if ca_o else None   # [n_ca, D, D]
         # site index of every cross-attention sub-block (for its gate)
         self.ca_sites = [i * len(self.kinds) + j for i in range(self.L) for j, k in enumerate(self.kinds) if k == "ca"]
+        # the same sub-block list as the host table drn_dit_forward walks (weights never move after load)
+        flat = [sb for subs in self.blocks for sb in subs]
+        self._subs_c = (N.DitSub * len(flat))()
+        for site, sb in enumerate(flat):
+            e = self._subs_c[site]
+            e.site, e.ca_index = site, -1
+            if sb["kind"] == "fa":
+                e.kind, e.w_a, e.w_b = N.SUB_FA, sb["wqkv"].data_ptr(), sb["wo"].data_ptr()
+                e.qn, e.kn = sb["qn"].data_ptr(), sb["kn"].data_ptr()
+            elif sb["kind"] == "ca":
+                e.kind, e.ca_index = N.SUB_CA, sb["idx"]
+            else:
+                e.kind, e.w_a, e.w_b = N.SUB_MLP, sb["w1"].data_ptr(), sb["w2"].data_ptr()
 
     # ------------------------------------------------------------------ per-timestep vectors (K10, K11)
     def prepare_timesteps(self, sigmas) -> None:
@@ -229,6 +245,11 @@ class HipDiT:
                   "y": torch.empty((B * S, self.w_final.shape[0]), dtype=bf, device=dev)}
             if self.exchange == "none":
                 ws["qkv"] = torch.empty((B * S, 3 * D), dtype=bf, device=dev)      # q | k | v, fused projection
+                lib = N.load_library()
+                nb = lib.drn_dit_forward_gemm_workspace_bytes(B, S, D, ws["u"].shape[1], self.w_final.shape[0], self.kpad)
+                ws["gemm_ws"] = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None      # split-K partials (few tokens)
+                nb = lib.drn_dit_forward_attn_workspace_bytes(B, self.heads, S)
+                ws["attn_ws"] = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None      # split-KV partials
             elif self.exchange == "a2a":
                 W = D // self.world                                                # columns of this rank's heads
                 ws["qb"] = torch.empty((rows, D), dtype=bf, device=dev)            # band projections: [rows][rank][W]
@@ -370,6 +391,34 @@ class HipDiT:
 
         # the latent is tiny: every rank patchifies it all and keeps its own token band
         P = N.patchify_concat(x, cond, self.with_mask, self.pt, self.ps, self.kpad)
+        if self.exchange == "none" and self.trace is None and not self._per_launch:
+            # one GPU: the whole launch sequence below is enqueued by ONE C call (csrc/dit_forward.hip: same kernels, same
+            # arguments, same order -> same bits; ~570 ctypes round trips less per forward)
+            a = N.DitForwardArgs()
+            a.S, a.B, a.D, a.hidden, a.heads = S, B, D, U.shape[1], self.heads
+            a.n_sub, a.subs = len(self._subs_c), self._subs_c
+            if B == 1:
+                a.shift, a.scale, a.gate = mod.data_ptr(), mod.data_ptr() + 2 * D, mod.data_ptr() + 4 * D
+                assert mod.stride(1) == 1
+                a.shift_site_stride = a.scale_site_stride = a.gate_site_stride = mod.stride(0)    # (rows of a batched sigma table)
+                a.final_shift, a.final_scale = modf.data_ptr(), modf.data_ptr() + 2 * D
+            else:
+                a.shift, a.scale, a.gate = modB.data_ptr(), modB.data_ptr() + 2 * B * D, gateB.data_ptr()
+                a.shift_site_stride = a.scale_site_stride = 2 * B * D
+                a.gate_site_stride = B * D
+                a.final_shift, a.final_scale = modfB.data_ptr(), modfB.data_ptr() + 2 * B * D
+            if addvec is not None:
+                a.addvec, a.addvec_stride = addvec.data_ptr(), addvec[0].numel()
+            a.cos, a.sin = cos.data_ptr(), sin.data_ptr()
+            a.P, a.kpad, a.w_patch = P.data_ptr(), self.kpad, self.w_patch.data_ptr()
+            a.w_final, a.n_final = self.w_final.data_ptr(), self.w_final.shape[0]
+            a.X, a.H, a.QKV, a.O, a.U, a.Y = (t.data_ptr() for t in (X, Hb, ws["qkv"], O, U, Y))
+            gws, aws = ws["gemm_ws"], ws["attn_ws"]
+            a.gemm_ws, a.gemm_ws_bytes = (gws.data_ptr(), gws.numel()) if gws is not None else (None, 0)
+            a.attn_ws, a.attn_ws_bytes = (aws.data_ptr(), aws.numel()) if aws is not None else (None, 0)
+            a.eps = 1e-6
+            N.dit_forward(a)
+            return N.unpatchify(Y, B, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)
         N.gemm(plan.band(P) if B == 1 else P, self.w_patch, out=X, rows_per_batch=rows)
 
         pending = None

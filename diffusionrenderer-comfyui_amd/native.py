@@ -5,7 +5,7 @@ There is NO fallback: if the shared library is missing or a call fails, this rai
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 import torch
 
@@ -17,8 +17,38 @@ ACT_NONE, ACT_SILU = 0, 1
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 
+SUB_FA, SUB_CA, SUB_MLP = 0, 1, 2
+
+
+class DitSub(Structure):                      # drn_dit_sub (include/drn.h)
+    _fields_ = [("kind", c_int32), ("site", c_int32), ("ca_index", c_int32), ("reserved", c_int32),
+                ("w_a", c_void_p), ("w_b", c_void_p), ("qn", c_void_p), ("kn", c_void_p)]
+
+
+class DitForwardArgs(Structure):              # drn_dit_forward_args (include/drn.h), field for field
+    _fields_ = [("struct_bytes", c_int64), ("S", c_int64), ("B", c_int64), ("D", c_int64), ("hidden", c_int64),
+                ("heads", c_int32), ("n_sub", c_int32), ("subs", POINTER(DitSub)),
+                ("shift", c_void_p), ("scale", c_void_p), ("gate", c_void_p),
+                ("shift_site_stride", c_int64), ("scale_site_stride", c_int64), ("gate_site_stride", c_int64),
+                ("addvec", c_void_p), ("addvec_stride", c_int64), ("cos", c_void_p), ("sin", c_void_p),
+                ("P", c_void_p), ("kpad", c_int64), ("w_patch", c_void_p),
+                ("final_shift", c_void_p), ("final_scale", c_void_p), ("w_final", c_void_p), ("n_final", c_int64),
+                ("X", c_void_p), ("H", c_void_p), ("QKV", c_void_p), ("O", c_void_p), ("U", c_void_p), ("Y", c_void_p),
+                ("gemm_ws", c_void_p), ("gemm_ws_bytes", c_int64), ("attn_ws", c_void_p), ("attn_ws_bytes", c_int64),
+                ("timer", c_void_p), ("eps", c_float), ("reserved", c_int32)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/drn.h one-to-one
 SIGNATURES = {
+    "drn_attention_plan": [_I, _L, _L, POINTER(c_int64)],
+    "drn_dit_forward": [POINTER(DitForwardArgs), _P],
+    "drn_dit_forward_gemm_workspace_bytes": [_L, _L, _L, _L, _L, _L],
+    "drn_dit_forward_attn_workspace_bytes": [_L, _I, _L],
+    "drn_timer_create": [_I, _I],
+    "drn_timer_destroy": [_P],
+    "drn_timer_count": [_P],
+    "drn_timer_seen": [_P, _I],
+    "drn_timer_read": [_P, _I, POINTER(c_int), POINTER(c_float), POINTER(c_double), POINTER(c_double)],
     "drn_abi_version": [],
     "drn_error_string": [_I],
     "drn_gemm_bf16": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _P],
@@ -45,7 +75,8 @@ SIGNATURES = {
     "drn_postprocess_u8": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64,
-             "drn_gemm_splitk_workspace_bytes": c_int64}
+             "drn_gemm_splitk_workspace_bytes": c_int64, "drn_dit_forward_gemm_workspace_bytes": c_int64,
+             "drn_dit_forward_attn_workspace_bytes": c_int64, "drn_timer_create": c_void_p, "drn_timer_destroy": None}
 
 
 def library_path() -> str:
@@ -109,6 +140,24 @@ class KernelTimer:
         self.sample_every = max(1, int(sample_every))
         self.counts = {}
         self.records = []          # (name, start_event, end_event, flops, bytes)
+        self._native = None        # drn_timer handle: launches enqueued by drn_dit_forward are bracketed in C
+
+    def native_handle(self, capacity=8192):
+        """The event pool drn_dit_forward records into (same sampling rule, kinds 0 = gemm, 1 = attention); None when this
+        timer does not watch those kernels."""
+        if not ({"gemm", "attention"} <= self.names):
+            return None
+        if self._native is None:
+            h = load_library().drn_timer_create(capacity, self.sample_every)
+            if not h:
+                raise RuntimeError("drn_timer_create failed")
+            self._native = c_void_p(h)
+        return self._native
+
+    def __del__(self):
+        if getattr(self, "_native", None) is not None and _LIB is not None:
+            _LIB.drn_timer_destroy(self._native)
+            self._native = None
 
     def begin(self, name):
         if name not in self.names:
@@ -137,9 +186,23 @@ class KernelTimer:
             d["ms_total"] += s.elapsed_time(e)
             d["flops"] += fl
             d["bytes"] += by
+        seen = dict(self.counts)
+        if self._native is not None:
+            lib = load_library()
+            kind, ms, fl, by = c_int(), c_float(), c_double(), c_double()
+            for i in range(lib.drn_timer_count(self._native)):
+                _check(lib.drn_timer_read(self._native, i, kind, ms, fl, by), "drn_timer_read")
+                name = ("gemm", "attention")[kind.value]
+                d = out.setdefault(name, {"launches": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0})
+                d["launches"] += 1
+                d["ms_total"] += ms.value
+                d["flops"] += fl.value
+                d["bytes"] += by.value
+            for k, name in enumerate(("gemm", "attention")):
+                seen[name] = seen.get(name, 0) + lib.drn_timer_seen(self._native, k)
         for name, d in out.items():
             d["ms_avg"] = d["ms_total"] / max(d["launches"], 1)
-            d["launches_seen"] = self.counts.get(name, d["launches"])      # all launches, timed or not
+            d["launches_seen"] = seen.get(name, d["launches"])      # all launches, timed or not
         return out
 
 
@@ -312,47 +375,16 @@ _NUM_CUS = 256          # MI355X
 _SPLIT_WS = {}
 
 
-def pick_kv_splits(batch, heads, Sq, Sk) -> int:
-    """Number of key chunks that best fills the CUs: one workgroup = (256 queries, 1 head, 1 chunk), one per CU at a time.
-    Minimises ceil(items / CUs) / nsplit (time in units of an unsplit workgroup); 1 when the unsplit grid already fits."""
-    blocks = batch * heads * ((Sq + 255) // 256)
-    best, best_cost = 1, float(-(-blocks // _NUM_CUS))
-    for n in (2, 4, 8):
-        if Sk // n < 512:
-            break
-        # measured on MI355X (tools/kbench.py --splits): ~4 % of an unsplit workgroup per extra workgroup (prologue, fp32
-        # partial store) and ~6 % for the combine pass
-        cost = -(-(blocks * n) // _NUM_CUS) * (1.0 / n + 0.04) + 0.06
-        if cost < min(best_cost, -(-blocks // _NUM_CUS) * 0.93):
-            best, best_cost = n, cost
-    return best
-
-
 def attention_plan(batch, heads, Sq, Sk):
-    """How to cover the (q-block, head) grid with whole rounds of the 256 CUs: a list of (q_begin, q_end, kv_splits).
-
-    One workgroup = 256 queries of one head and owns a CU for its whole key range, so `blocks` workgroups take
-    ceil(blocks / 256) rounds and a fractional last round idles CUs (1152 blocks = 4.5 rounds cost 5).  Plan: the q-blocks
-    that fill whole rounds run unsplit; the remaining q-blocks (< 1 round of workgroups) run as a second launch with their
-    keys cut into chunks (split-KV + combine) so that they, too, fill the CUs.  Costs from pick_kv_splits' measured model."""
-    per_qb = batch * heads
-    nqb = (Sq + 255) // 256
-    blocks = nqb * per_qb
-    n_all = pick_kv_splits(batch, heads, Sq, Sk)
-    cost_all = float(-(-blocks // _NUM_CUS)) if n_all == 1 else -(-(blocks * n_all) // _NUM_CUS) * (1.0 / n_all + 0.04) + 0.06
-    rounds = blocks // _NUM_CUS
-    nqb_main = (rounds * _NUM_CUS) // per_qb
-    if rounds == 0 or nqb_main == 0 or nqb_main == nqb:
-        return [(0, Sq, n_all)]
-    q_cut = nqb_main * 256
-    n_tail = pick_kv_splits(batch, heads, Sq - q_cut, Sk)
-    tail_blocks = (nqb - nqb_main) * per_qb
-    cost_tail = (float(-(-tail_blocks // _NUM_CUS)) if n_tail == 1
-                 else -(-(tail_blocks * n_tail) // _NUM_CUS) * (1.0 / n_tail + 0.04) + 0.06)
-    cost_two = -(-(nqb_main * per_qb) // _NUM_CUS) + cost_tail + 0.02          # + the launch boundary
-    if cost_two < cost_all:
-        return [(0, q_cut, 1), (q_cut, Sq, n_tail)]
-    return [(0, Sq, n_all)]
+    """How to cover the (q-block, head) grid of ONE clip with whole rounds of the 256 CUs: a list of (q_begin, q_end, kv_splits)
+    from drn_attention_plan (csrc/dit_forward.hip: the same plan drn_dit_forward uses).  The q-blocks that fill whole rounds run
+    unsplit; a fractional last round runs as a second launch with its keys cut into chunks (split-KV + combine).  `batch` is
+    ignored on purpose: the plan of one clip applies to every clip of a batch (batch-invariant summation order)."""
+    buf = (c_int64 * 6)()
+    n = load_library().drn_attention_plan(heads, Sq, Sk, buf)
+    if n <= 0:
+        raise ValueError(f"no attention plan for heads={heads} Sq={Sq} Sk={Sk}")
+    return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
 
 
 def attention(q, k, v, out=None, heads=None, scale=None, kv_splits=None):
@@ -452,3 +484,14 @@ def postprocess_u8(video, normalize_normal: bool):
     _check(load_library().drn_postprocess_u8(_ptr(video), _ptr(out), B, T, H, W, 1 if normalize_normal else 0, _stream()),
            "drn_postprocess_u8")
     return out
+
+
+def dit_forward(args: "DitForwardArgs"):
+    """Enqueue one whole DiT forward (drn_dit_forward).  `args` holds raw pointers: the caller keeps every tensor alive."""
+    args.struct_bytes = ctypes.sizeof(DitForwardArgs)
+    if _TIMER is not None:
+        h = _TIMER.native_handle()
+        args.timer = h.value if h is not None else None
+    else:
+        args.timer = None
+    _check(load_library().drn_dit_forward(ctypes.byref(args), _stream()), "drn_dit_forward")

@@ -151,6 +151,62 @@ int drn_attention_splitkv_bf16(const void* q, const void* k, const void* v, void
                                float scale, int nsplit, void* workspace, void* stream);
 int64_t drn_attention_splitkv_workspace_bytes(int batch, int heads, int64_t Sq, int nsplit);
 
+/* ---- how drn_dit_forward / the host wrapper cover the (q-block, head) grid of ONE clip with whole rounds of the 256 CUs:
+ * plan[3 i + {0,1,2}] = (q_begin, q_end, kv_splits) for launch i; returns the number of launches (1 or 2).  The q-blocks that
+ * fill whole rounds run unsplit, a fractional last round runs as a second launch with its keys split (split-KV + combine).
+ * Host-only (no GPU needed).  No reference counterpart (the reference calls F.scaled_dot_product_attention). */
+int drn_attention_plan(int heads, int64_t Sq, int64_t Sk, int64_t* plan);
+
+/* ---- one whole CleanGeneralDIT forward on one GPU, enqueued by ONE call: patch-embed GEMM, n_sub sub-blocks
+ * ({FA, CA, MLP} x 28), final LayerNorm + Linear.  Replaces the module loop of CleanGeneralDIT.py:686-706 (x_embedder,
+ * `for block in self.blocks.values()`, final_layer) as a SEQUENCER: every launch is one of the kernels above with the arguments
+ * the per-launch host path passes (dit_engine.HipDiT._run), so the results are bit-identical to it; ~570 launches cost the host
+ * ~2 ms from here instead of 4-7 ms through ctypes.  Patchify before and unpatchify after stay separate calls.
+ * B clips of S tokens are stacked along the rows (row = b S + s; attention runs per clip).  All pointers device memory. */
+#define DRN_SUB_FA 0     /* self-attention sub-block      CleanGeneralDIT.py:465-517 with block_type "FA" */
+#define DRN_SUB_CA 1     /* cross-attention sub-block: one key -> softmax == 1 -> x += bf16(gate * to_out(to_v(ctx))) */
+#define DRN_SUB_MLP 2    /* GPT-2 feed-forward sub-block  CleanGeneralDIT.py:442-462 */
+typedef struct drn_dit_sub {
+    int32_t kind;        /* DRN_SUB_* */
+    int32_t site;        /* AdaLN site: row of the shift / scale / gate tables */
+    int32_t ca_index;    /* CA: row of `addvec`; else -1 */
+    int32_t reserved;
+    const void* w_a;     /* FA: fused q|k|v weights [3D, D];  MLP: layer1 [hidden, D] */
+    const void* w_b;     /* FA: to_out [D, D];               MLP: layer2 [D, hidden] */
+    const void* qn;      /* FA: RMSNorm weight of q [128] */
+    const void* kn;      /* FA: RMSNorm weight of k [128] */
+} drn_dit_sub;
+typedef struct drn_dit_forward_args {
+    int64_t struct_bytes;                 /* sizeof(drn_dit_forward_args): ABI check */
+    int64_t S, B;                         /* tokens per clip, clips */
+    int64_t D, hidden;                    /* model width (heads x 128), MLP width */
+    int32_t heads, n_sub;
+    const drn_dit_sub* subs;              /* HOST array of n_sub entries */
+    const void* shift; const void* scale; const void* gate;     /* AdaLN vectors: site s at base + s * site_stride, [B or 1][D] rows */
+    int64_t shift_site_stride, scale_site_stride, gate_site_stride;       /* in elements */
+    const void* addvec; int64_t addvec_stride;                  /* CA: bf16(gate * c_i) rows, entry i at addvec + i * stride, [B or 1][D] */
+    const void* cos; const void* sin;     /* RoPE tables [S, 128] */
+    const void* P; int64_t kpad; const void* w_patch;           /* patchified input [B S, kpad], patch-embed weight [D, kpad] */
+    const void* final_shift; const void* final_scale; const void* w_final; int64_t n_final;   /* final layer; w_final [n_final, D] */
+    void* X; void* H; void* QKV; void* O; void* U; void* Y;     /* activations: [B S, D] x2, [B S, 3D], [B S, D], [B S, hidden], [B S, n_final] */
+    void* gemm_ws; int64_t gemm_ws_bytes;                       /* split-K partials (drn_dit_forward_gemm_workspace_bytes) */
+    void* attn_ws; int64_t attn_ws_bytes;                       /* split-KV partials (drn_dit_forward_attn_workspace_bytes) */
+    void* timer;                          /* drn_timer_create handle or NULL */
+    float eps; int32_t reserved;
+} drn_dit_forward_args;
+int drn_dit_forward(const drn_dit_forward_args* args, void* stream);
+int64_t drn_dit_forward_gemm_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t hidden, int64_t n_final, int64_t kpad);
+int64_t drn_dit_forward_attn_workspace_bytes(int64_t B, int heads, int64_t S);
+
+/* ---- per-launch timing inside drn_dit_forward (the roofline leg of bench.py; no reference counterpart): a pool of HIP event
+ * pairs; every `sample_every`-th GEMM (kind 0) and attention (kind 1) call of a forward is bracketed on the launch stream.
+ * Read after the stream is synchronised.  The one object this library allocates, owned by the caller via create / destroy. */
+void* drn_timer_create(int capacity, int sample_every);
+void drn_timer_destroy(void* timer);
+int drn_timer_count(void* timer);
+int drn_timer_seen(void* timer, int kind);
+int drn_timer_read(void* timer, int index, int* kind, float* ms, double* flops, double* bytes);
+
 /* ---- patchify + channel concat: out[b*T*H*W + (t,h,w), (c r m n)] gathered from x | cond | ones-mask
  * (CleanGeneralDIT.py:669-675, :409-414).  x: [B,Cx,Tl,Hl,Wl], cond: [B,Cc,Tl,Hl,Wl] bf16; with_mask appends the
  * all-ones channel; columns [C*pt*ps*ps, ldo) are zero-filled (K padding for the GEMM).  Bit-exact index op. */

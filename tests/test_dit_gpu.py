@@ -190,3 +190,70 @@ def test_full_model_cfg3_batch_and_determinism(pkg, gpu, full28_dit):
     print(f"cfg3 full model: batched vs single rel-L2 {e0:.2e} / {e1:.2e}; clip 0 vs clip 1 {rel_l2(y0.cpu(), y1.cpu()):.2e}")
     assert torch.equal(yb[:1], y0) and torch.equal(yb[1:], y1)
     assert rel_l2(y0.cpu(), y1.cpu()) > 0.1
+
+
+@pytest.mark.parametrize("D,L,heads,lat,B", [(256, 2, 2, (2, 16, 16), 1), (256, 2, 2, (2, 16, 16), 3), (512, 1, 4, (1, 32, 32), 2),
+                                               (1024, 1, 8, (2, 64, 64), 1)])
+def test_forward_sequencer_equals_per_launch_path(pkg, gpu, D, L, heads, lat, B):
+    """drn_dit_forward (ONE C call enqueues patch embed, every sub-block and the final layer; the default on one GPU) against the
+    per-launch host path (one ctypes call per kernel; what the traces of the golden tests above and the sharded engine run):
+    same kernels, same arguments, same order -> the same bits.  S = 128 / 256 (split-K GEMMs + workspaces) and 2048."""
+    net = tiny_net(pkg, D, L, heads)
+    sw = pkg.synthetic_weights
+    sd = sw.synth_state_dict(net, torch.bfloat16, device=gpu)
+    x = sw.synth_tensor("seq.x", (B, 16) + lat, torch.float32, device=gpu, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor("seq.c", (B, 16) + lat, torch.float32, device=gpu, scale=1.0).to(torch.bfloat16)
+    ci = [3, 0, 4][:B]
+    seq = pkg.dit_engine.HipDiT(net, sd, device=gpu)
+    per = pkg.dit_engine.HipDiT(net, sd, device=gpu)
+    per._per_launch = True
+    assert not seq._per_launch
+    # several sigmas prepared at once: the AdaLN table of one sigma is then a strided view (site stride = n_sigmas x 3D)
+    for eng in (seq, per):
+        eng.prepare_timesteps([80.0, 1.7, 0.02])
+    for sigma in (1.7, 80.0):
+        y_seq = seq(x, torch.tensor(sigma), cond, ci)
+        y_per = per(x, torch.tensor(sigma), cond, ci)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y_seq.float()).all()
+        assert torch.equal(y_seq, y_per), f"sigma {sigma}: max |diff| {(y_seq.float() - y_per.float()).abs().max().item()}"
+
+
+def test_forward_sequencer_matches_reference_golden(pkg, gpu):
+    """The golden of the two-block tiny model through the sequencer path (no trace): same bound as the per-launch path."""
+    fixture, tag, D, L, heads, forward = CASES[1]
+    gold, meta = load_golden(fixture)
+    net = tiny_net(pkg, D, L, heads, forward)
+    sw = pkg.synthetic_weights
+    sd = sw.synth_state_dict(net, torch.bfloat16, device=gpu)
+    F_, h, w = json.loads(meta["latent"])
+    x = sw.synth_tensor(tag + ".x", (1, 16, F_, h, w), torch.float32, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor(tag + ".cond", (1, net["additional_concat_ch"], F_, h, w), torch.float32, scale=1.0).to(torch.bfloat16)
+    dit = pkg.dit_engine.HipDiT(net, sd, device=gpu)
+    assert dit.trace is None and not dit._per_launch
+    y = dit(x.to(gpu), torch.tensor(float(meta["sigma"])), cond.to(gpu), torch.full((1, 1), int(meta["context_index"]), dtype=torch.long)).cpu()
+    e_ref, e_hip = rel_l2(gold["out.bf16"], gold["out.fp32_tables_bf16"]), rel_l2(y, gold["out.fp32_tables_bf16"])
+    print(f"{tag} (sequencer): e_ref={e_ref:.3e} e_hip={e_hip:.3e}")
+    assert e_hip <= 1.5 * e_ref + 1e-3
+
+
+def test_kernel_timer_sees_sequencer_launches(pkg, gpu):
+    """bench.py's roofline leg: with a KernelTimer set, drn_dit_forward brackets every n-th GEMM / attention call with HIP events."""
+    net = tiny_net(pkg, 256, 2, 2)
+    sw = pkg.synthetic_weights
+    sd = sw.synth_state_dict(net, torch.bfloat16, device=gpu)
+    x = sw.synth_tensor("tm.x", (1, 16, 2, 16, 16), torch.float32, device=gpu, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor("tm.c", (1, 16, 2, 16, 16), torch.float32, device=gpu).to(torch.bfloat16)
+    dit = pkg.dit_engine.HipDiT(net, sd, device=gpu)
+    dit(x, torch.tensor(2.0), cond, 1)
+    timer = pkg.native.KernelTimer(sample_every=3)
+    pkg.native.set_timer(timer)
+    try:
+        dit(x, torch.tensor(2.0), cond, 1)
+    finally:
+        pkg.native.set_timer(None)
+    torch.cuda.synchronize()
+    summ = timer.summary()
+    # per forward: patch embed + 2 x (qkv, out, mlp1, mlp2) + final = 10 GEMM calls, 2 attention calls
+    assert summ["gemm"]["launches_seen"] == 10 and summ["gemm"]["launches"] == 4 and summ["gemm"]["ms_total"] > 0
+    assert summ["attention"]["launches_seen"] == 2 and summ["attention"]["launches"] == 1 and summ["attention"]["flops"] > 0

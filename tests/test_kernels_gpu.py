@@ -662,15 +662,6 @@ def test_attention_planned_tail_matches_single_pass(pkg, gpu):
     _attn_check(auto, _attn_ref(q, k, v, heads), "planned tail")
 
 
-def test_pick_kv_splits(pkg):
-    f = pkg.native.pick_kv_splits
-    assert f(1, 32, 18432, 18432) == 1          # 2304 workgroups = 9 full rounds
-    assert f(1, 32, 2304, 18432) == 4           # 288 workgroups (2 rounds at 56 %) -> 1152 (4.5 -> 5 quarter rounds)
-    assert f(1, 32, 4608, 18432) == 4
-    assert f(1, 32, 9216, 18432) == 1
-    assert f(1, 2, 128, 128) == 1
-
-
 def test_permute_021_bit_exact(pkg, gpu):
     x = torch.randn(37, 8, 1536, device=gpu).to(torch.bfloat16)
     y = pkg.native.permute_021(x)
