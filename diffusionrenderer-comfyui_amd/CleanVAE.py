@@ -108,6 +108,7 @@ class HipCosmosTokenizer:
         One small all-gather of the two edge rows of every rank (T x (W+2) x C each); the neighbours' rows are picked out."""
         from .parallel import allgather_stack
         assert x.halo == 1
+        x.dirty_halo()                                                                # (its halo rows are about to hold data)
         edges = torch.stack([x.t[:, 1], x.t[:, x.H]], 0)                              # [2, T, W+2, C]
         allv = allgather_stack(edges, self.pg)                                         # [world, 2, T, W+2, C]
         if self.rank > 0:
@@ -180,6 +181,11 @@ class HipCosmosTokenizer:
             return torch.cat([self.encode(video[i:i + 1], bands) for i in range(B)], 0)
         if (T - 1) % 8 != 0 or H % 8 != 0 or W % 8 != 0:
             raise ValueError(f"CV8x8x8 tokenizer needs T = 8k+1 frames and H, W multiples of 8, got {(T, H, W)}")
+        with V.pooled_buffers():
+            return self._encode(video, bands)
+
+    def _encode(self, video, bands):
+        B, C, T, H, W = video.shape
         cfg = self.cfg
         self._bands = self.world if (bands is None and self.world > 1 and (H // 8) % self.world == 0) else 1
         if self._bands > 1:                                           # this rank's band of image rows
@@ -220,6 +226,10 @@ class HipCosmosTokenizer:
         B = z.shape[0]
         if B != 1:
             return torch.cat([self.decode(z[i:i + 1], bands) for i in range(B)], 0)
+        with V.pooled_buffers():
+            return self._decode(z, bands)
+
+    def _decode(self, z, bands):
         cfg = self.cfg
         hl = z.shape[3]
         self._bands = self.world if (bands is None and self.world > 1 and hl % self.world == 0) else 1

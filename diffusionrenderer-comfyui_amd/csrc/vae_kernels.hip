@@ -372,10 +372,69 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = threadIdx.x; i < ldp; i += 256) pr[i] = i < n ? f2bf(expf(sr[i] - m) * inv) : (bf16_t)0;
 }
 
+// the same softmax with the row held in registers: ONE read of the fp32 scores (the kernel above reads them three times - 1.0 GB per
+// 9216 x 9216 frame of the mid-block attention against 0.34 GB here).  One workgroup per row, thread t owns the 16-byte vectors
+// t, t + 256, ...: n <= 1024 * VPT, n % 4 == 0, 16-byte aligned rows.  Same max / exp / normalise arithmetic as above (the fp32 row
+// sum is taken over a different partition of the row).
+template <int VPT>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int n,
+                                                               int64_t ld, int64_t ldp) {
+    const int64_t row = blockIdx.x;
+    const float4* sr = reinterpret_cast<const float4*>(s + row * ld);
+    const int nv = n >> 2;
+    __shared__ float red[4];
+    float4 v[VPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < nv) {
+            v[j] = sr[i];
+            m = fmaxf(fmaxf(m, fmaxf(v[j].x, v[j].y)), fmaxf(v[j].z, v[j].w));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < nv) {
+            v[j].x = expf(v[j].x - m); v[j].y = expf(v[j].y - m); v[j].z = expf(v[j].z - m); v[j].w = expf(v[j].w - m);
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / sum;
+    uint2* pr = reinterpret_cast<uint2*>(p + row * ldp);
+    const int nvp = (int)(ldp >> 2);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < nv) pr[i] = make_uint2(pack_bf2(v[j].x * inv, v[j].y * inv), pack_bf2(v[j].z * inv, v[j].w * inv));
+        else if (i < nvp) pr[i] = make_uint2(0u, 0u);
+    }
+    for (int i = threadIdx.x + 256 * VPT; i < nvp; i += 256) pr[i] = make_uint2(0u, 0u);
+}
+
 extern "C" int drn_softmax_rows(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, void* stream) {
     DRN_CHECK_ARG(scores && probs && rows >= 0 && n > 0 && ld >= n && ldp >= n && rows < (1ll << 31));
     if (rows == 0) return DRN_OK;
-    softmax_rows_kernel<<<dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = n % 4 == 0 && ld % 4 == 0 && ldp % 4 == 0 && ((uintptr_t)scores & 15) == 0 && ((uintptr_t)probs & 7) == 0;
+#define SM_LAUNCH(V) softmax_rows_reg_kernel<V><<<dim3((unsigned)rows), dim3(256), 0, st>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp)
+    if (vec && n <= 1024 * 4) SM_LAUNCH(4);
+    else if (vec && n <= 1024 * 9) SM_LAUNCH(9);          // 9216 keys: a 72 x 128 latent frame (the headline clip)
+    else if (vec && n <= 1024 * 16) SM_LAUNCH(16);
+    else softmax_rows_kernel<<<dim3((unsigned)rows), dim3(256), 0, st>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp);
+#undef SM_LAUNCH
     return drn_launch_status();
 }
 

@@ -30,16 +30,59 @@ N._RESTYPES["drn_groupnorm_workspace_bytes"] = c_int64
 BF = torch.bfloat16
 
 
-class CL:
-    """Channels-last activation [T][H+2*halo][W+2*halo][C] bf16 with a zero halo (interior-only writes keep it zero)."""
+# Activation buffers whose halo is known to be zero, by (shape, device): every kernel writes interior pixels only, so a buffer that
+# was zero-filled once keeps a zero halo for life and the next activation of that shape takes it over as it is.  Before round 3
+# every activation was a fresh torch.zeros: 435 fills of up to 99 MB per encode + decode at the headline clip (6 ms of 46).
+_POOL = {}
+_POOL_ON = [False]          # on inside HipCosmosTokenizer.encode / decode only: nothing there keeps `.t` of a dead activation
 
-    __slots__ = ("t", "T", "H", "W", "C", "halo")
+
+def pool_clear():
+    _POOL.clear()
+
+
+class pooled_buffers:
+    """with pooled_buffers(): activations allocated inside recycle zero-halo buffers of their shape."""
+
+    def __enter__(self):
+        self.prev = _POOL_ON[0]
+        _POOL_ON[0] = True
+
+    def __exit__(self, *exc):
+        _POOL_ON[0] = self.prev
+        return False
+
+
+class CL:
+    """Channels-last activation [T][H+2*halo][W+2*halo][C] bf16 with a zero halo (interior-only writes keep it zero).
+    Buffers allocated here go back to a per-shape pool when the activation dies (same stream: the next writer is ordered behind
+    the last reader); `dirty_halo()` takes a buffer out of that cycle (the band-sharded tokenizer writes neighbour rows into it)."""
+
+    __slots__ = ("t", "T", "H", "W", "C", "halo", "_key")
 
     def __init__(self, T, H, W, C, halo=1, device=None, tensor=None):
         self.T, self.H, self.W, self.C, self.halo = T, H, W, C, halo
+        self._key = None
         if tensor is None:
-            tensor = torch.zeros((T, H + 2 * halo, W + 2 * halo, C), dtype=BF, device=device)
+            shape = (T, H + 2 * halo, W + 2 * halo, C)
+            if halo and _POOL_ON[0]:
+                key = (shape, torch.device(device) if device is not None else None)
+                free = _POOL.get(key)
+                tensor = free.pop() if free else torch.zeros(shape, dtype=BF, device=device)
+                self._key = key
+            elif halo:
+                tensor = torch.zeros(shape, dtype=BF, device=device)
+            else:
+                tensor = torch.empty(shape, dtype=BF, device=device)      # no halo: every element is written
         self.t = tensor
+
+    def dirty_halo(self):
+        self._key = None
+
+    def __del__(self):
+        key = getattr(self, "_key", None)
+        if key is not None and _POOL is not None:
+            _POOL.setdefault(key, []).append(self.t)
 
     def interior(self):
         h = self.halo

@@ -178,6 +178,43 @@ def test_dense_gemm_softmax_transpose(pkg, gpu):
     assert rel_l2(o, p.float()[:, :100] @ v.float()) < 3e-3
 
 
+@pytest.mark.parametrize("n,ldp", [(100, 128), (2304, 2304), (4100, 4160), (9216, 9216), (16384, 16384), (16388, 16448), (4098, 4160)])
+def test_softmax_rows_register_and_three_pass_kernels(pkg, gpu, n, ldp):
+    """drn_softmax_rows: rows of up to 4096 / 9216 / 16384 scores stay in registers (one read of the fp32 scores), longer or
+    unaligned rows take the three-pass kernel; both against torch.softmax, padding columns zero."""
+    V = pkg.native_vae
+    g = torch.Generator().manual_seed(n)
+    s = (torch.randn(37, n, generator=g) * 3.0).to(gpu)
+    p = V.softmax_rows(s, n, ldp)
+    ref = torch.softmax(s, -1)
+    assert p.shape == (37, ldp) and (p[:, n:] == 0).all()
+    assert torch.allclose(p[:, :n].float(), ref, atol=4e-3, rtol=8e-3)
+    assert (p[:, :n].float().sum(-1) - 1).abs().max().item() < 2e-2
+
+
+def test_pooled_activation_buffers_keep_a_zero_halo(pkg, gpu):
+    """Inside encode / decode activations recycle buffers of their shape instead of a fresh torch.zeros each; two encodes of
+    different clips must not leak into each other and must equal the un-pooled result bit for bit."""
+    V = pkg.native_vae
+    sw = pkg.synthetic_weights
+    vae = pkg.CleanVAE.CleanVAE(state_dict=sw.synth_vae_state_dict(device=gpu), device=gpu)
+    a = sw.synth_tensor("pool.a", (1, 3, 9, 32, 48), torch.float32, device=gpu).to(torch.bfloat16)
+    b = sw.synth_tensor("pool.b", (1, 3, 9, 32, 48), torch.float32, device=gpu).to(torch.bfloat16)
+    V.pool_clear()
+    za, zb = vae.encode(a), vae.encode(b)
+    ya = vae.decode(za)
+    assert len(V._POOL) > 0 and all(t.dtype == torch.bfloat16 for free in V._POOL.values() for t in free)
+    for free in V._POOL.values():               # every pooled buffer still has its zero halo
+        for t in free:
+            assert (t[:, 0] == 0).all() and (t[:, -1] == 0).all() and (t[:, :, 0] == 0).all() and (t[:, :, -1] == 0).all()
+    za2 = vae.encode(a)                         # recycled buffers, same bits
+    assert torch.equal(za, za2) and not torch.equal(za, zb)
+    V.pool_clear()
+    enc, dec = vae.model._encode, vae.model._decode       # the same work without the pool
+    assert not V._POOL_ON[0]
+    assert torch.equal(enc(a, None), za) and torch.equal(dec(za, None), ya) and len(V._POOL) == 0
+
+
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_silu(pkg, gpu, silu):
     V = pkg.native_vae
