@@ -27,7 +27,7 @@ import torch
 
 from . import native as N
 from .host_tables import rope_cos_sin, timestep_sinusoid
-from .parallel import ShardPlan, allgather_rows_, alltoall_rows_, group_info, wait_exchange
+from .parallel import ShardPlan, allgather_rows_, alltoall_bands_, alltoall_rows_, group_info, wait_exchange
 
 
 def _pad_cols(w: torch.Tensor, mult: int) -> torch.Tensor:
@@ -92,6 +92,8 @@ class HipDiT:
         # DRN_PER_LAUNCH=1: one ctypes call per kernel (the path the sharded engine and the traces use) instead of the
         # drn_dit_forward sequencer - same kernels, same bits (tests compare the two)
         self._per_launch = os.environ.get("DRN_PER_LAUNCH", "0") == "1"
+        # DRN_SP_SPLIT_RETURN=0: the return all-to-all as ONE collective after the whole attention (A/B runs)
+        self._split_return = os.environ.get("DRN_SP_SPLIT_RETURN", "1") != "0"
 
     # ------------------------------------------------------------------ weights
     def _load(self, sd, p):
@@ -473,9 +475,26 @@ class HipDiT:
                         N.qk_norm_rope(None, k, None, sb["kn"], cos, sin, hpr, tokens_per_batch=S)
                         wait_exchange(work_q, "a2a q")
                         N.qk_norm_rope(rq, None, sb["qn"], None, cos, sin, hpr, tokens_per_batch=S)
-                        N.attention(rq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
-                        work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
-                        wait_exchange(work, "a2a o (return)")
+                        # heads -> tokens.  The attention of a rank's heads is usually two launches (native.attention_plan: the
+                        # q-blocks that fill whole rounds of the CUs, then the rest with its keys split): the token bands whose
+                        # queries the first launch has finished go home while the second one runs, only the last bands' slabs
+                        # (1 of 8 at world 8) travel exposed.  Same launches as the single call: same bits.
+                        aplan = N.attention_plan(1, hpr, S, S)
+                        nb = aplan[0][1] // rows if len(aplan) == 2 else 0             # complete bands of the first launch
+                        if nb >= 1 and self._split_return:
+                            (_, q_cut, ns0), (_, _, ns1) = aplan
+                            N.attention(rq[:q_cut].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh[:q_cut].unsqueeze(0),
+                                        heads=hpr, kv_splits=ns0)
+                            work0 = alltoall_bands_(Oh.view(world, rows, W), oback, 0, nb, self.pg, async_op=True)
+                            N.attention(rq[q_cut:].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh[q_cut:].unsqueeze(0),
+                                        heads=hpr, kv_splits=ns1)
+                            work1 = alltoall_bands_(Oh.view(world, rows, W), oback, nb, world, self.pg, async_op=True)
+                            wait_exchange(work0, "a2a o (return, under the attention tail)")
+                            wait_exchange(work1, "a2a o (return)")
+                        else:
+                            N.attention(rq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
+                            work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
+                            wait_exchange(work, "a2a o (return)")
                         if fused:
                             N.gemm_blocked(oback, sb["wo"], X, rows, epilogue=N.EPI_GATE_RES, gate=gate, residual=X, a_planes=True)
                             continue

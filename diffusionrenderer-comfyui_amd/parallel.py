@@ -138,6 +138,32 @@ def alltoall_rows_(send: torch.Tensor, recv: torch.Tensor, group=None, async_op:
     return dist.all_to_all_single(recv, send, group=group, async_op=async_op)
 
 
+def alltoall_bands_(send: torch.Tensor, recv: torch.Tensor, lo: int, hi: int, group=None, async_op: bool = False):
+    """The part of alltoall_rows_(send, recv) whose DESTINATION ranks are lo <= r < hi: every rank sends slab r to rank r for those
+    r only; a rank inside [lo, hi) receives its slab from every peer (all of `recv`), the others receive nothing.  The parts
+    over a partition of the ranks add up to the whole exchange - used to return the attention output of the token bands whose
+    queries are finished while the attention of the remaining bands still runs (dit_engine, head <-> token exchange)."""
+    assert send.is_contiguous() and recv.is_contiguous() and send.shape == recv.shape
+    world, n = send.shape[0], send.shape[1]
+    rank = dist.get_rank(group)
+    assert 0 <= lo <= hi <= world
+    if lo == hi:
+        return None
+    tail = tuple(send.shape[2:])
+    inp = send.view(world * n, *tail)[lo * n:hi * n]
+    mine = lo <= rank < hi
+    out = recv.view(world * n, *tail) if mine else recv.view(world * n, *tail)[:0]
+    in_splits = [n if lo <= r < hi else 0 for r in range(world)]
+    out_splits = [n if mine else 0] * world
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        host = torch.empty(out.shape, dtype=recv.dtype)                # test-only path, see alltoall_rows_
+        dist.all_to_all_single(host, inp.cpu(), out_splits, in_splits, group=group)
+        if mine:
+            out.copy_(host)
+        return None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
 def allgather_stack(local: torch.Tensor, group=None) -> torch.Tensor:
     """local [k, ...] on every rank (same k) -> [world, k, ...] in rank order."""
     world = dist.get_world_size(group)

@@ -141,6 +141,15 @@ def _worker(rank, world, port, q):
         rcv = torch.empty_like(snd)
         par.alltoall_rows_(snd, rcv, dist.group.WORLD)
         ok_gather = ok_gather and all(bool((rcv[r] == r + rank * 10).all()) for r in range(world))
+        # the exchange in two parts by destination rank (the return all-to-all sent under the attention tail): parts add up to the whole
+        for cut in (0, 1, world):
+            rcv2 = torch.full_like(snd, -1.0)
+            w0 = par.alltoall_bands_(snd, rcv2, 0, cut, dist.group.WORLD, async_op=True)
+            w1 = par.alltoall_bands_(snd, rcv2, cut, world, dist.group.WORLD, async_op=True)
+            for w in (w0, w1):
+                if w is not None:
+                    w.wait()
+            ok_gather = ok_gather and torch.equal(rcv2, rcv)
         q.put((rank, err, ok_gather))
     finally:
         dist.destroy_process_group()
