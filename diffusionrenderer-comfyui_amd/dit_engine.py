@@ -316,10 +316,7 @@ class HipDiT:
         Tp, Hp, Wp = F_ // self.pt, h // self.ps, w // self.ps
         S = Tp * Hp * Wp
         rank, world = group_info(self.pg) if self.pg is not None else (0, 1)
-        if B > 1 and self.exchange != "none":
-            # token-band sharding is per clip; a sharded job walks the clips (each still spans every rank)
-            return torch.cat([self.forward(x[b:b + 1], sigma, cond[b:b + 1], cis[b]) for b in range(B)], 0)
-        plan = ShardPlan(S, rank, world)
+        plan = ShardPlan(S, rank, world)          # (a sharded batch: every clip is cut into the same token bands, rows = b * band + r)
 
         mod, modf = self.time_vectors(sigma)
         addvec = None
@@ -377,6 +374,76 @@ class HipDiT:
             return X.clone()
         return (X.view(B, -1, X.shape[1]) + pending.view(B, 1, -1)).view_as(X)
 
+    def _fa_sharded(self, sb, Hb, X, O, ws, plan, cos, sin, gate, fused):
+        """Self-attention sub-block of ONE clip's token band with an exchange (Hb: modulated input rows, X: residual stream rows,
+        updated in place; O: scratch rows)."""
+        D = self.D
+        S, rows, world = plan.S, plan.rows, plan.world
+        if self.exchange == "a2a":
+            # tokens -> heads: project the band, regroup rank-major, all-to-all; norm + RoPE + attention over all S
+            # tokens of this rank's heads; heads -> tokens: all-to-all back, regroup, output projection.
+            # K|V go first so their exchange (RCCL's stream, 2/3 of the bytes) overlaps the Q projection.
+            W, hpr = D // world, self.heads // world
+            Oh, oback, rq, rkv = ws["oh"], ws["oback"], ws["rq"], ws["rkv"]
+            # (the projections write the rank-major send slabs themselves where the tile kernel can; else a regroup pass)
+            if fused:
+                N.gemm_blocked(Hb, sb["wqkv"][D:], ws["skv"], rows, c_planes=True)
+            else:
+                N.gemm(Hb, sb["wqkv"][D:], out=ws["kvb"])
+                N.permute_021(ws["kvb"].view(rows, world, 2 * W), out=ws["skv"])
+            work_kv = alltoall_rows_(ws["skv"], rkv.view(world, rows, 2 * W), self.pg, async_op=True)
+            if fused:
+                N.gemm_blocked(Hb, sb["wqkv"][:D], ws["sq"], rows, c_planes=True)
+            else:
+                N.gemm(Hb, sb["wqkv"][:D], out=ws["qb"])
+                N.permute_021(ws["qb"].view(rows, world, W), out=ws["sq"])
+            work_q = alltoall_rows_(ws["sq"], rq.view(world, rows, W), self.pg, async_op=True)
+            wait_exchange(work_kv, "a2a k|v")
+            k, v = rkv[:, :W], rkv[:, W:]
+            N.qk_norm_rope(None, k, None, sb["kn"], cos, sin, hpr, tokens_per_batch=S)
+            wait_exchange(work_q, "a2a q")
+            N.qk_norm_rope(rq, None, sb["qn"], None, cos, sin, hpr, tokens_per_batch=S)
+            # heads -> tokens.  The attention of a rank's heads is usually two launches (native.attention_plan: the
+            # q-blocks that fill whole rounds of the CUs, then the rest with its keys split): the token bands whose
+            # queries the first launch has finished go home while the second one runs, only the last bands' slabs
+            # (1 of 8 at world 8) travel exposed.  Same launches as the single call: same bits.
+            aplan = N.attention_plan(1, hpr, S, S)
+            nb = aplan[0][1] // rows if len(aplan) == 2 else 0             # complete bands of the first launch
+            if nb >= 1 and self._split_return:
+                (_, q_cut, ns0), (_, _, ns1) = aplan
+                N.attention(rq[:q_cut].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh[:q_cut].unsqueeze(0),
+                            heads=hpr, kv_splits=ns0)
+                work0 = alltoall_bands_(Oh.view(world, rows, W), oback, 0, nb, self.pg, async_op=True)
+                N.attention(rq[q_cut:].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh[q_cut:].unsqueeze(0),
+                            heads=hpr, kv_splits=ns1)
+                work1 = alltoall_bands_(Oh.view(world, rows, W), oback, nb, world, self.pg, async_op=True)
+                wait_exchange(work0, "a2a o (return, under the attention tail)")
+                wait_exchange(work1, "a2a o (return)")
+            else:
+                N.attention(rq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
+                work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
+                wait_exchange(work, "a2a o (return)")
+            if fused:
+                N.gemm_blocked(oback, sb["wo"], X, rows, epilogue=N.EPI_GATE_RES, gate=gate, residual=X, a_planes=True)
+                return
+            N.permute_021(oback, out=O.view(rows, world, W))
+        else:
+            # local projections; K|V land directly in this rank's band of the gather buffer.  K|V first, so the
+            # exchange (RCCL's own stream) overlaps the Q projection + q-norm; wait() orders attention after it.
+            q, KV = ws["q"], ws["kv"]
+            kv_loc = plan.band(KV)
+            N.gemm(Hb, sb["wqkv"][D:], out=kv_loc)
+            N.qk_norm_rope(None, kv_loc[:, :D], None, sb["kn"], cos, sin, self.heads,
+                           tokens_per_batch=rows, pos_offset=plan.start)
+            work = allgather_rows_(KV, plan, self.pg, async_op=True)     # the one exchange of the block (xGMI)
+            N.gemm(Hb, sb["wqkv"][:D], out=q)
+            N.qk_norm_rope(q, None, sb["qn"], None, cos, sin, self.heads,
+                           tokens_per_batch=rows, pos_offset=plan.start)
+            wait_exchange(work, "gather k|v")
+            k, v = KV[:, :D], KV[:, D:]
+            N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
+        N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gate, residual=X)
+
     def _run(self, x, cond, mod, modf, addvec, Tp, Hp, Wp, plan):
         """The kernel sequence of one forward (all shapes / pointers fixed for a given input shape -> capturable)."""
         D = self.D
@@ -421,7 +488,12 @@ class HipDiT:
             a.eps = 1e-6
             N.dit_forward(a)
             return N.unpatchify(Y, B, self.out_ch, Tp, Hp, Wp, self.pt, self.ps)
-        N.gemm(plan.band(P) if B == 1 else P, self.w_patch, out=X, rows_per_batch=rows)
+        sharded = self.exchange != "none"
+        if sharded and B > 1:
+            for b in range(B):                                   # this rank's band of every clip (P holds whole clips)
+                N.gemm(plan.band(P[b * S:(b + 1) * S]), self.w_patch, out=X[b * rows:(b + 1) * rows])
+        else:
+            N.gemm(plan.band(P) if B == 1 else P, self.w_patch, out=X, rows_per_batch=rows)
 
         pending = None
         site = 0
@@ -449,79 +521,23 @@ class HipDiT:
                         N.gemm(Hb, sb["wqkv"], out=QKV, rows_per_batch=rows)
                         q, k, v = QKV[:, :D], QKV[:, D:2 * D], QKV[:, 2 * D:]
                         N.qk_norm_rope(q, k, sb["qn"], sb["kn"], cos, sin, self.heads, tokens_per_batch=S)
-                    elif self.exchange == "a2a":
-                        # tokens -> heads: project the band, regroup rank-major, all-to-all; norm + RoPE + attention over all S
-                        # tokens of this rank's heads; heads -> tokens: all-to-all back, regroup, output projection.
-                        # K|V go first so their exchange (RCCL's stream, 2/3 of the bytes) overlaps the Q projection.
-                        W, hpr = D // world, self.heads // world
-                        Oh, oback, rq, rkv = ws["oh"], ws["oback"], ws["rq"], ws["rkv"]
-                        # (the projections write the rank-major send slabs themselves where the tile kernel can; else a regroup pass)
+                        if B == 1:
+                            N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
+                        else:
+                            Q3 = QKV.view(B, S, 3 * D)
+                            N.attention(Q3[:, :, :D], Q3[:, :, D:2 * D], Q3[:, :, 2 * D:], out=O.view(B, S, D), heads=self.heads)
+                        N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gateB[site - 1] if B > 1 else gate, residual=X,
+                               rows_per_batch=rows)
+                    else:
+                        # sharded: the exchanges (and the projections that write / read their slabs) run clip by clip on this
+                        # rank's band of each clip; every clip of a batch has the same sigma, hence the same gate row
                         if fused is None:
-                            fused = world > 1 and W >= 512 and N.gemm_blocked_ok(rows, 2 * D) and N.gemm_blocked_ok(rows, D)
-                        if fused:
-                            N.gemm_blocked(Hb, sb["wqkv"][D:], ws["skv"], rows, c_planes=True)
-                        else:
-                            N.gemm(Hb, sb["wqkv"][D:], out=ws["kvb"])
-                            N.permute_021(ws["kvb"].view(rows, world, 2 * W), out=ws["skv"])
-                        work_kv = alltoall_rows_(ws["skv"], rkv.view(world, rows, 2 * W), self.pg, async_op=True)
-                        if fused:
-                            N.gemm_blocked(Hb, sb["wqkv"][:D], ws["sq"], rows, c_planes=True)
-                        else:
-                            N.gemm(Hb, sb["wqkv"][:D], out=ws["qb"])
-                            N.permute_021(ws["qb"].view(rows, world, W), out=ws["sq"])
-                        work_q = alltoall_rows_(ws["sq"], rq.view(world, rows, W), self.pg, async_op=True)
-                        wait_exchange(work_kv, "a2a k|v")
-                        k, v = rkv[:, :W], rkv[:, W:]
-                        N.qk_norm_rope(None, k, None, sb["kn"], cos, sin, hpr, tokens_per_batch=S)
-                        wait_exchange(work_q, "a2a q")
-                        N.qk_norm_rope(rq, None, sb["qn"], None, cos, sin, hpr, tokens_per_batch=S)
-                        # heads -> tokens.  The attention of a rank's heads is usually two launches (native.attention_plan: the
-                        # q-blocks that fill whole rounds of the CUs, then the rest with its keys split): the token bands whose
-                        # queries the first launch has finished go home while the second one runs, only the last bands' slabs
-                        # (1 of 8 at world 8) travel exposed.  Same launches as the single call: same bits.
-                        aplan = N.attention_plan(1, hpr, S, S)
-                        nb = aplan[0][1] // rows if len(aplan) == 2 else 0             # complete bands of the first launch
-                        if nb >= 1 and self._split_return:
-                            (_, q_cut, ns0), (_, _, ns1) = aplan
-                            N.attention(rq[:q_cut].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh[:q_cut].unsqueeze(0),
-                                        heads=hpr, kv_splits=ns0)
-                            work0 = alltoall_bands_(Oh.view(world, rows, W), oback, 0, nb, self.pg, async_op=True)
-                            N.attention(rq[q_cut:].unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh[q_cut:].unsqueeze(0),
-                                        heads=hpr, kv_splits=ns1)
-                            work1 = alltoall_bands_(Oh.view(world, rows, W), oback, nb, world, self.pg, async_op=True)
-                            wait_exchange(work0, "a2a o (return, under the attention tail)")
-                            wait_exchange(work1, "a2a o (return)")
-                        else:
-                            N.attention(rq.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=Oh.unsqueeze(0), heads=hpr)
-                            work = alltoall_rows_(Oh.view(world, rows, W), oback, self.pg, async_op=True)
-                            wait_exchange(work, "a2a o (return)")
-                        if fused:
-                            N.gemm_blocked(oback, sb["wo"], X, rows, epilogue=N.EPI_GATE_RES, gate=gate, residual=X, a_planes=True)
-                            continue
-                        N.permute_021(oback, out=O.view(rows, world, W))
-                    else:
-                        # local projections; K|V land directly in this rank's band of the gather buffer.  K|V first, so the
-                        # exchange (RCCL's own stream) overlaps the Q projection + q-norm; wait() orders attention after it.
-                        q, KV = ws["q"], ws["kv"]
-                        kv_loc = plan.band(KV)
-                        N.gemm(Hb, sb["wqkv"][D:], out=kv_loc)
-                        N.qk_norm_rope(None, kv_loc[:, :D], None, sb["kn"], cos, sin, self.heads,
-                                       tokens_per_batch=rows, pos_offset=plan.start)
-                        work = allgather_rows_(KV, plan, self.pg, async_op=True)     # the one exchange of the block (xGMI)
-                        N.gemm(Hb, sb["wqkv"][:D], out=q)
-                        N.qk_norm_rope(q, None, sb["qn"], None, cos, sin, self.heads,
-                                       tokens_per_batch=rows, pos_offset=plan.start)
-                        wait_exchange(work, "gather k|v")
-                        k, v = KV[:, :D], KV[:, D:]
-                    if self.exchange == "a2a":
-                        pass
-                    elif B == 1:
-                        N.attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), out=O.unsqueeze(0), heads=self.heads)
-                    else:
-                        Q3 = QKV.view(B, S, 3 * D)
-                        N.attention(Q3[:, :, :D], Q3[:, :, D:2 * D], Q3[:, :, 2 * D:], out=O.view(B, S, D), heads=self.heads)
-                    N.gemm(O, sb["wo"], out=X, epilogue=N.EPI_GATE_RES, gate=gateB[site - 1] if B > 1 else gate, residual=X,
-                           rows_per_batch=rows)
+                            W_ = D // world
+                            fused = (self.exchange == "a2a" and world > 1 and W_ >= 512 and N.gemm_blocked_ok(rows, 2 * D)
+                                     and N.gemm_blocked_ok(rows, D))
+                        for b in range(B):
+                            band = slice(b * rows, (b + 1) * rows)
+                            self._fa_sharded(sb, Hb[band], X[band], O[band], ws, plan, cos, sin, gate, fused)
                 else:
                     N.gemm(Hb, sb["w1"], out=U, epilogue=N.EPI_GELU, rows_per_batch=rows)
                     N.gemm(U, sb["w2"], out=X, epilogue=N.EPI_GATE_RES, gate=gateB[site - 1] if B > 1 else gate, residual=X,
@@ -533,6 +549,12 @@ class HipDiT:
             N.ln_modulate(X, modf[:D], modf[D:], out=Hb, add_vec=pending)
             N.gemm(Hb, self.w_final, out=plan.band(Y))
             allgather_rows_(Y, plan, self.pg)                       # 2.4 MB at cfg 3: every rank gets the full latent
+        elif sharded:
+            N.ln_modulate(X, modfB[0], modfB[1], out=Hb, add_vec=pending, rows_per_batch=rows)
+            for b in range(B):
+                Yb = Y[b * S:(b + 1) * S]
+                N.gemm(Hb[b * rows:(b + 1) * rows], self.w_final, out=plan.band(Yb))
+                allgather_rows_(Yb, plan, self.pg)
         else:
             N.ln_modulate(X, modfB[0], modfB[1], out=Hb, add_vec=pending, rows_per_batch=rows)
             N.gemm(Hb, self.w_final, out=Y, rows_per_batch=rows)

@@ -70,7 +70,17 @@ def _worker(rank, world, port, q, exchange, wide=False):
             rel = float((y1.float() - y2.float()).norm() / y1.float().norm())
             assert rel < 2e-3, rel
             y1 = y3
-        q.put((rank, bool(torch.equal(y1, y2)), float((y1.float() - y2.float()).abs().max())))
+        same = bool(torch.equal(y1, y2))
+        if wide != "clip":
+            # two clips stepped as ONE sharded batch (token-local ops batched over the clips, the exchanges clip by clip) against
+            # the same two clips run one after the other: bit for bit (SURVEY.md 8f N1 under sequence parallelism)
+            xb = torch.cat([x, sw.synth_tensor("pg.x2", (1, 16) + lat, torch.float32, scale=2.0).to(torch.bfloat16).to(dev)], 0)
+            cb = torch.cat([cond, sw.synth_tensor("pg.c2", (1, 16) + lat, torch.float32, scale=1.0).to(torch.bfloat16).to(dev)], 0)
+            yb = sharded(xb, torch.tensor(1.7), cb, [2, 4])
+            y_one = torch.cat([sharded(xb[i:i + 1], torch.tensor(1.7), cb[i:i + 1], ci) for i, ci in enumerate([2, 4])], 0)
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(yb, y_one)) and bool(torch.equal(yb[:1], y2)) and not bool(torch.equal(yb[:1], yb[1:]))
+        q.put((rank, same, float((y1.float() - y2.float()).abs().max())))
     finally:
         dist.destroy_process_group()
 
