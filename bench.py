@@ -280,6 +280,15 @@ def main():
             # the failure exits with PROBE_FAILED_RC and the launcher starts a fresh run with the all-gather exchange
             try:
                 dist.all_to_all_single(torch.empty_like(probe), probe)
+                # ... and the uneven form the return exchange uses (parallel.alltoall_bands_: slabs for ranks < world - 1 first)
+                if world > 1:
+                    pr2 = probe.view(world, 1024)
+                    pkg_par = load_package().parallel
+                    back = torch.empty_like(pr2)
+                    for lo, hi in ((0, world - 1), (world - 1, world)):
+                        w_ = pkg_par.alltoall_bands_(pr2, back, lo, hi, pg, async_op=True)
+                        if w_ is not None:
+                            w_.wait()
                 torch.cuda.synchronize()
             except Exception as e:                                       # noqa: BLE001 - any transport error
                 print(f"[bench] rank {rank}: all_to_all_single failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)

@@ -5,8 +5,42 @@
 #include "drn_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm (no affine) + AdaLN modulate, optional broadcast pre-add.  One wave per row.
+// LayerNorm (no affine) + AdaLN modulate, optional broadcast pre-add.
 // CleanGeneralDIT.py:7-11, :481, :506, :517 (rounding points: SURVEY.md Appendix C).
+//
+// A row is NCH chunk columns of 64 lanes x 8 elements (chunk i of lane l = elements (l + 64 i) * 8 .. + 7).  Two kernels share ONE
+// summation tree for the mean and the variance, so they return the same bits and the launcher may pick either by row count:
+//     per lane and chunk: the 8 elements in order;  per lane and GROUP of NCH / 4 chunks: the chunks in order;
+//     per group: the 64-lane butterfly;  total = (G0 + G1) + (G2 + G3).
+//   * ln_modulate_kernel<NCH>:   one wave per row (a row stays in one wave's registers) - many rows;
+//   * ln_modulate_kernel4<NCH>:  four waves per row, wave w owns group w, partial sums meet in LDS - few rows (cfg 1: 256 rows
+//     on 64 workgroups of the one-wave kernel took 11.7 us per call, a chain of three memory round trips on a quarter of the CUs).
+// NCH < 4 (D <= 1024: the tiny test networks) keeps a single butterfly and has no four-wave form.
+template <int NCH>
+__device__ __forceinline__ float ln_tree_sum(const float (&part)[NCH]) {
+    if (NCH < 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) s += part[i];
+        return wave_sum(s);
+    }
+    constexpr int G = NCH >= 4 ? NCH / 4 : 1;
+    float g[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < G; ++i) t += part[(NCH >= 4 ? w * G : 0) + i];
+        g[w] = t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                   // four independent butterflies, interleaved
+#pragma unroll
+        for (int w = 0; w < 4; ++w) g[w] += __shfl_xor(g[w], o, 64);
+    }
+    return (g[0] + g[1]) + (g[2] + g[3]);
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
                                                           const bf16_t* __restrict__ shift,
@@ -19,10 +53,11 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(bf16_t* __restrict__ x
     bf16_t* xr = x + row * D;
     const bf16_t* ar = add ? add + b * D : nullptr;
     float v[NCH][8];
-    float s = 0.f;
+    float part[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
+        float s = 0.f;
         if (c < D) {
             uint4 raw = *reinterpret_cast<const uint4*>(xr + c);
             unpack8(raw, v[i]);
@@ -39,12 +74,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(bf16_t* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
+        part[i] = s;
     }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
+    const float mean = ln_tree_sum<NCH>(part) / (float)D;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
+        float q = 0.f;
         if (c < D) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -52,8 +88,9 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(bf16_t* __restrict__ x
                 q += d * d;
             }
         }
+        part[i] = q;
     }
-    const float var = wave_sum(q) / (float)D;
+    const float var = ln_tree_sum<NCH>(part) / (float)D;
     const float rstd = 1.0f / sqrtf(var + eps);
     const bf16_t* sh = shift + b * D;
     const bf16_t* sc = scale + b * D;
@@ -76,21 +113,108 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(bf16_t* __restrict__ x
     }
 }
 
+// four waves per row: wave w owns chunks w * G .. w * G + G - 1 (G = NCH / 4); D must fill all NCH chunk columns' lanes or leave
+// whole lanes empty exactly as above (c < D test per chunk)
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_kernel4(bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
+                                                           const bf16_t* __restrict__ shift,
+                                                           const bf16_t* __restrict__ scale, bf16_t* __restrict__ h,
+                                                           int64_t rows, int D, int64_t rpb, float eps) {
+    static_assert(NCH >= 4 && NCH % 4 == 0, "four-wave form needs whole chunk groups");
+    constexpr int G = NCH / 4;
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t b = row / rpb;
+    bf16_t* xr = x + row * D;
+    const bf16_t* ar = add ? add + b * D : nullptr;
+    const bf16_t* sh = shift + b * D;
+    const bf16_t* sc = scale + b * D;
+    float v[G][8], fs[G][8], fc[G][8];
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = (lane + 64 * (w * G + g)) * 8;
+        float s = 0.f;
+        if (c < D) {
+            unpack8(*reinterpret_cast<const uint4*>(xr + c), v[g]);
+            unpack8(*reinterpret_cast<const uint4*>(sh + c), fs[g]);     // (independent of the statistics: in flight with the row)
+            unpack8(*reinterpret_cast<const uint4*>(sc + c), fc[g]);
+            if (ar) {
+                float a[8];
+                unpack8(*reinterpret_cast<const uint4*>(ar + c), a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[g][j] = rbf(v[g][j] + a[j]);
+                *reinterpret_cast<uint4*>(xr + c) = pack8(v[g]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[g][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] = 0.f;
+        }
+        t += s;
+    }
+    t = wave_sum(t);
+    if (lane == 0) red[0][w] = t;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+    float tq = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = (lane + 64 * (w * G + g)) * 8;
+        float q = 0.f;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[g][j] - mean;
+                q += d * d;
+            }
+        }
+        tq += q;
+    }
+    tq = wave_sum(tq);
+    if (lane == 0) red[1][w] = tq;
+    __syncthreads();
+    const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    bf16_t* hr = h + row * D;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = (lane + 64 * (w * G + g)) * 8;
+        if (c < D) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = rbf((v[g][j] - mean) * rstd);
+                const float s1 = rbf(1.0f + fc[g][j]);
+                o[j] = rbf(rbf(n * s1) + fs[g][j]);
+            }
+            *reinterpret_cast<uint4*>(hr + c) = pack8(o);
+        }
+    }
+}
+
+static int g_ln_force = -1;      // tests: 0 = one wave per row always, 1 = four waves per row wherever it exists, -1 = by row count
+extern "C" void drn_ln_force_kernel(int which) { g_ln_force = which; }
+
 extern "C" int drn_ln_modulate(void* x, const void* add_vec, const void* shift, const void* scale, void* h,
                                int64_t rows, int64_t D, int64_t rows_per_batch, float eps, void* stream) {
     DRN_CHECK_ARG(x && shift && scale && h && rows >= 0 && D > 0 && D % 8 == 0 && D <= 8192 && rows_per_batch > 0);
     if (rows == 0) return DRN_OK;
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)((D + 511) / 512);
-#define LAUNCH(N)                                                                                                     \
-    ln_modulate_kernel<N><<<grid, block, 0, st>>>((bf16_t*)x, (const bf16_t*)add_vec, (const bf16_t*)shift,          \
-                                                  (const bf16_t*)scale, (bf16_t*)h, rows, (int)D, rows_per_batch, eps)
-    if (nch <= 1) LAUNCH(1);
-    else if (nch <= 2) LAUNCH(2);
-    else if (nch <= 4) LAUNCH(4);
-    else if (nch <= 8) LAUNCH(8);
-    else LAUNCH(16);
+    // few rows: four waves per row (same bits as one wave per row: shared summation tree) - 4 x the waves in flight
+    const bool four = nch > 2 && rows < (1ll << 31) && (g_ln_force == 1 || (g_ln_force < 0 && rows <= 4096));
+    dim3 grid(four ? (unsigned)rows : (unsigned)((rows + 3) / 4)), block(256);
+#define LAUNCH(K, N)                                                                                                  \
+    K<N><<<grid, block, 0, st>>>((bf16_t*)x, (const bf16_t*)add_vec, (const bf16_t*)shift, (const bf16_t*)scale,      \
+                                 (bf16_t*)h, rows, (int)D, rows_per_batch, eps)
+    if (nch <= 1) LAUNCH(ln_modulate_kernel, 1);
+    else if (nch <= 2) LAUNCH(ln_modulate_kernel, 2);
+    else if (nch <= 4) { if (four) LAUNCH(ln_modulate_kernel4, 4); else LAUNCH(ln_modulate_kernel, 4); }
+    else if (nch <= 8) { if (four) LAUNCH(ln_modulate_kernel4, 8); else LAUNCH(ln_modulate_kernel, 8); }
+    else { if (four) LAUNCH(ln_modulate_kernel4, 16); else LAUNCH(ln_modulate_kernel, 16); }
 #undef LAUNCH
     return drn_launch_status();
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     "drn_gemm_force_tile": [_I],
     "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "drn_ln_modulate": [_P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
+    "drn_ln_force_kernel": [_I],
     "drn_bcast_add": [_P, _P, _L, _L, _L, _P],
     "drn_permute_021": [_P, _P, _L, _L, _L, _P],
     "drn_rmsnorm": [_P, _P, _P, _L, _L, _F, _P],
@@ -76,7 +77,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64,
              "drn_gemm_splitk_workspace_bytes": c_int64, "drn_dit_forward_gemm_workspace_bytes": c_int64,
-             "drn_dit_forward_attn_workspace_bytes": c_int64, "drn_timer_create": c_void_p, "drn_timer_destroy": None}
+             "drn_dit_forward_attn_workspace_bytes": c_int64, "drn_timer_create": c_void_p, "drn_timer_destroy": None,
+             "drn_ln_force_kernel": None}
 
 
 def library_path() -> str:

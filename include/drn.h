@@ -109,6 +109,9 @@ int drn_gemv_bf16(const void* x, const void* W, void* y, int64_t N, int64_t K,
  * x,h: [rows, D] bf16; shift/scale/add_vec: [batches, D] bf16; batch = row / rows_per_batch. D % 8 == 0, D <= 8192. */
 int drn_ln_modulate(void* x, const void* add_vec, const void* shift, const void* scale, void* h,
                     int64_t rows, int64_t D, int64_t rows_per_batch, float eps, void* stream);
+/* tuning hook (tests / A-B runs; no reference counterpart): the row statistics come from ONE summation tree that a
+ * one-wave-per-row and a four-waves-per-row kernel share (same bits); -1 = chosen by row count, 0 / 1 force either. */
+void drn_ln_force_kernel(int which);
 
 /* ---- x[rows,D] <- bf16(x + vec[batch,:]) (stand-alone broadcast residual; same arithmetic as above) */
 int drn_bcast_add(void* x, const void* vec, int64_t rows, int64_t D, int64_t rows_per_batch, void* stream);

@@ -131,6 +131,34 @@ def test_ln_modulate_matches_oracle(pkg, gpu, rows, D):
     assert ok, msg
 
 
+@pytest.mark.parametrize("rows,D,with_add", [(256, 4096, False), (300, 4096, True), (7, 2048, True), (130, 8192, False), (513, 3072, True)])
+def test_ln_modulate_four_waves_per_row_equals_one_wave_per_row(pkg, gpu, rows, D, with_add):
+    """The two LayerNorm kernels (one wave per row for many rows, four waves per row for few) share one summation tree: same
+    bits, so the launcher may pick by row count - and both stay within 1 ulp of the reference ops."""
+    lib = pkg.native.load_library()
+    x = rnd((rows, D), gpu, 2.0, seed=170)
+    B = 2 if rows % 2 == 0 else 1
+    shift, scale = rnd((B, D), gpu, 0.7, seed=171), rnd((B, D), gpu, 0.7, seed=172)
+    add = rnd((B, D), gpu, 0.5, seed=173) if with_add else None
+    outs, xs = {}, {}
+    for which in (0, 1):
+        lib.drn_ln_force_kernel(which)
+        try:
+            xs[which] = x.clone()
+            outs[which] = pkg.native.ln_modulate(xs[which], shift, scale, add_vec=add, rows_per_batch=rows // B)
+        finally:
+            lib.drn_ln_force_kernel(-1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(xs[0], xs[1])
+    x2 = x.cpu().float()
+    if with_add:
+        x2 = (x.cpu() + add.cpu().repeat_interleave(rows // B, 0)).float()
+        assert torch.equal(xs[1].cpu().float(), x2)
+    n = F.layer_norm(x2.to(BF).unsqueeze(1), (D,), eps=1e-6)
+    ref = torch.cat([O.modulate(n[b * (rows // B):(b + 1) * (rows // B)], shift[b:b + 1].cpu(), scale[b:b + 1].cpu()) for b in range(B)], 0).squeeze(1)
+    ok, msg = ulp_diff_ok(outs[1].cpu(), ref, max_ulp=1, frac_exact=0.995)
+    assert ok, msg
+
+
 def test_ln_modulate_with_broadcast_add(pkg, gpu):
     rows, D = 129, 512
     x = rnd((rows, D), gpu, 2.0, seed=20)

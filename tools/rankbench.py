@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--blocks", type=int, default=28)
     ap.add_argument("--tokenizer", action="store_true", help="time this rank's band of the tokenizer instead of the DiT")
+    ap.add_argument("--clips", type=int, default=1, help="clips stepped as one sharded batch (the node's 5 G-buffer passes)")
     args = ap.parse_args()
     os.environ["DRN_SP_EXCHANGE"] = args.exchange
     pkg = load_package()
@@ -65,7 +66,12 @@ def main():
         if full.shape[0] == plan.S and plan.world > 1:
             full.view(plan.world, plan.rows, -1)[1:].copy_(plan.band(full).unsqueeze(0).expand(plan.world - 1, -1, -1))
 
+    def fake_bands(send, recv, lo, hi, pg=None, async_op=False):
+        if hi > lo:
+            recv[lo:hi].copy_(send[lo:hi])
+
     eng.alltoall_rows_ = fake_alltoall
+    eng.alltoall_bands_ = fake_bands
     eng.allgather_rows_ = fake_allgather
     dev = torch.device("cuda", 0)
     if args.tokenizer:
@@ -75,8 +81,8 @@ def main():
     sw = pkg.synthetic_weights
     dit = eng.HipDiT(net, sw.synth_state_dict(net, torch.bfloat16, device=dev), device=dev, process_group=object())
     F_, h, w = (args.frames - 1) // 8 + 1, args.height // 8, args.width // 8
-    x = sw.synth_tensor("rb.x", (1, 16, F_, h, w), torch.float32, device=dev, scale=2.0).to(torch.bfloat16)
-    cond = sw.synth_tensor("rb.c", (1, 16, F_, h, w), torch.float32, device=dev, scale=1.0).to(torch.bfloat16)
+    x = sw.synth_tensor("rb.x", (args.clips, 16, F_, h, w), torch.float32, device=dev, scale=2.0).to(torch.bfloat16)
+    cond = sw.synth_tensor("rb.c", (args.clips, 16, F_, h, w), torch.float32, device=dev, scale=1.0).to(torch.bfloat16)
     sig = [80.0 * 0.8 ** i for i in range(args.steps + 1)]
     dit.prepare_timesteps(sig)
     dit(x, sig[0], cond, 3)
@@ -98,7 +104,7 @@ def main():
     dit(x, sig[1], cond, 3)
     torch.cuda.synchronize()
     N.set_timer(None)
-    print(f"world={world} exchange={dit.exchange}: {ms:.2f} ms per forward on this rank's shapes (no communication); "
+    print(f"world={world} exchange={dit.exchange} clips={args.clips}: {ms:.2f} ms per forward on this rank's shapes (no communication); "
           f"host enqueue {host_ms:.2f} ms per forward")
     for name, d in timer.summary().items():
         n = d["launches_seen"]
