@@ -487,7 +487,7 @@ def main():
                 traffic = json.load(f)["families"][dom]["bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
-        roofline = {"bound": "mfma", "kernel": {"gemm": "gemm256s_kernel" if world == 1 else "gemm144_kernel", "attention": "attention_fwd_kernel"}[dom],
+        roofline = {"bound": "mfma", "kernel": {"gemm": "gemm256s_kernel" if world == 1 else "gemm144_kernel", "attention": "attention16_fwd_kernel" if os.environ.get("DRN_ATT16", "1") != "0" else "attention_fwd_kernel"}[dom],
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch (L2-miss traffic incl. Infinity-Cache hits)",

@@ -22,6 +22,7 @@
 //     S(t) = softmax(t)          ~160 VALU + the tile prefetch DMA, no MFMA
 //     interval 2t:   G0 runs M(t),  G1 runs S(t-1)   | barrier |   interval 2t+1:  G0 runs S(t),  G1 runs M(t)   | barrier
 // so on every SIMD one wave feeds the matrix pipe while its partner's VALU work fills the issue slots between its MFMAs.
+#include <stdlib.h>
 #include "drn_common.h"
 
 // Build switches (A/B timing of variants in one process: tools/kbench.py --lib; the shipped library uses the defaults):
@@ -587,6 +588,19 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
     *reinterpret_cast<uint32_t*>(O + b * bso + row * ldo + (int64_t)head * 128 + 2 * lane) = pack_bf2(o0 * inv, o1 * inv);
 }
 
+// attention16.hip: the same kernel on v_mfma_f32_16x16x32_bf16 (same grid, same arguments)
+void drn_attention16_launch(const void* q, const void* k, const void* v, void* o, int heads, int64_t Sq, int64_t Sk, int64_t ldq,
+                            int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                            float scale_log2e, int nqb, int64_t total, int nsplit, int64_t kv_chunk, float* opart, float* mlpart,
+                            hipStream_t st);
+// default since round 3: the 16x16x32 body (tools/kbench.py attn --shapes 0,1: 4.21-4.33 vs 4.46-4.62 ms at cfg 3, in the model
+// 121.8 vs 124.6 ms of attention per step; both bodies pass the same tests).  DRN_ATT16=0 selects the 32x32x16 body below.
+#ifndef ATT_DEFAULT_SHAPE16
+#define ATT_DEFAULT_SHAPE16 1
+#endif
+static int g_att16 = -1;       // -1: DRN_ATT16 from the environment (default ATT_DEFAULT_SHAPE16); 0 / 1 forced (tests, A/B)
+extern "C" void drn_attention_force_shape16(int on) { g_att16 = on; }
+
 static int attention_launch(const void* q, const void* k, const void* v, void* o, int batch, int heads, int64_t Sq, int64_t Sk,
                             int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv,
                             int64_t bso, float scale, int nsplit, void* workspace, void* stream) {
@@ -610,7 +624,15 @@ static int attention_launch(const void* q, const void* k, const void* v, void* o
     float* opart = (float*)workspace;
     float* mlpart = opart ? opart + (int64_t)nsplit * batch * Sq * heads * 128 : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    // gridDim.y carries the batch count for the partial layout (blocks are indexed by x only)
+    static int env16 = -1;
+    if (env16 < 0) {
+        const char* e = getenv("DRN_ATT16");
+        env16 = e ? (e[0] != '0') : ATT_DEFAULT_SHAPE16;
+    }
+    if (g_att16 >= 0 ? g_att16 : env16) {
+        drn_attention16_launch(q, k, v, o, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale_log2e, (int)nqb, total, nsplit,
+                               kv_chunk, opart, mlpart, st);
+    } else
     attention_fwd_kernel<<<dim3((unsigned)total, 1, 1), dim3(512), 0, st>>>(
         (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, heads, Sq, Sk, ldq, ldk, ldv, ldo, bsq, bsk,
         bsv, bso, scale_log2e, (int)nqb, (int)total, nsplit, kv_chunk, opart, mlpart);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "drn_attention_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P],
     "drn_attention_splitkv_bf16": [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _I, _P, _P],
     "drn_attention_splitkv_workspace_bytes": [_I, _I, _L, _I],
+    "drn_attention_force_shape16": [_I],
     "drn_patchify_concat": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "drn_unpatchify": [_P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "drn_edm_scale_input": [_P, _P, _L, _F, _P],
@@ -78,7 +79,7 @@ SIGNATURES = {
 _RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64,
              "drn_gemm_splitk_workspace_bytes": c_int64, "drn_dit_forward_gemm_workspace_bytes": c_int64,
              "drn_dit_forward_attn_workspace_bytes": c_int64, "drn_timer_create": c_void_p, "drn_timer_destroy": None,
-             "drn_ln_force_kernel": None}
+             "drn_ln_force_kernel": None, "drn_attention_force_shape16": None}
 
 
 def library_path() -> str:

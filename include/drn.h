@@ -143,6 +143,11 @@ int drn_attention_bf16(const void* q, const void* k, const void* v, void* o,
                        int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
                        float scale, void* stream);
 
+/* tuning hook (tests / A-B runs; no reference counterpart): the kernel body on v_mfma_f32_16x16x32_bf16 (csrc/attention16.hip)
+ * instead of 32x32x16; -1 = DRN_ATT16 from the environment / the build default, 0 / 1 forced.  Same arithmetic contract, a
+ * different (equally valid) fp32 summation order. */
+void drn_attention_force_shape16(int on);
+
 /* ---- same attention with the keys cut into `nsplit` chunks (flash-decoding style): every (q-block, head, chunk) is a
  * workgroup writing an un-normalised fp32 partial into `workspace`, a second kernel merges them.  Arithmetic per chunk is
  * that of drn_attention_bf16; used when (q-blocks x heads) under-fills the 256 CUs, e.g. the 2304-query token bands of

@@ -31,6 +31,15 @@ def ulp_diff_ok(out, ref, max_ulp=1, frac_exact=0.98, atol_rel=2e-3, mag=None):
     return bad == 0 and exact >= frac_exact, f"bad={bad} exact={exact:.5f}"
 
 
+@pytest.fixture(params=["32x32x16", "16x16x32"])
+def att_body(request, pkg):
+    """Every attention test runs on both kernel bodies (csrc/attention.hip, csrc/attention16.hip)."""
+    lib = pkg.native.load_library()
+    lib.drn_attention_force_shape16(1 if request.param == "16x16x32" else 0)
+    yield request.param
+    lib.drn_attention_force_shape16(-1)
+
+
 def rnd(shape, dev, scale=1.0, seed=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(BF).to(dev)
@@ -242,7 +251,7 @@ def _attn_check(out, ref, tag, rel=ATTN_REL_L2, max_ulp=2, frac_exact=0.5):
 
 
 @pytest.mark.parametrize("heads,Sq,Sk", [(2, 256, 256), (2, 128, 128), (4, 300, 300), (1, 513, 77), (32, 256, 1024), (2, 512, 4160)])
-def test_attention_matches_fp32(pkg, gpu, heads, Sq, Sk):
+def test_attention_matches_fp32(pkg, gpu, heads, Sq, Sk, att_body):
     q = rnd((1, Sq, heads * 128), gpu, seed=29)
     k = rnd((1, Sk, heads * 128), gpu, seed=30)
     v = rnd((1, Sk, heads * 128), gpu, seed=31)
@@ -250,7 +259,7 @@ def test_attention_matches_fp32(pkg, gpu, heads, Sq, Sk):
     _attn_check(out, _attn_ref(q, k, v, heads), f"h{heads} Sq{Sq} Sk{Sk}")
 
 
-def test_attention_exact_integers_asymmetric(pkg, gpu):
+def test_attention_exact_integers_asymmetric(pkg, gpu, att_body):
     """Small-integer Q/K/V with a softmax that is exactly one-hot (one key per query scores far above the rest): O must be
     that key's V row bit for bit - catches any permutation slip in the K / V^T fragment order, the DMA swizzles and the
     LDS-transposed epilogue (asymmetric data: every row and column differs)."""
@@ -275,7 +284,7 @@ def test_attention_exact_integers_asymmetric(pkg, gpu):
     assert (out.float() - v[:, perm].float()).abs().max().item() < 1e-18, "softmax is one-hot here: O[i] == V[perm[i]]"
 
 
-def test_attention_strided_qkv_buffer(pkg, gpu):
+def test_attention_strided_qkv_buffer(pkg, gpu, att_body):
     heads, S = 2, 320
     D = heads * 128
     qkv = rnd((S, 3 * D), gpu, seed=32)
@@ -284,7 +293,7 @@ def test_attention_strided_qkv_buffer(pkg, gpu):
     _attn_check(out, _attn_ref(q, k, v, heads), "strided qkv")
 
 
-def test_attention_online_softmax_rescale_spike(pkg, gpu):
+def test_attention_online_softmax_rescale_spike(pkg, gpu, att_body):
     """Force the running max to jump at a late KV tile (guide rule 26): one key strongly aligned with one query."""
     heads, S = 1, 512
     q = rnd((1, S, 128), gpu, 0.3, seed=33)
@@ -296,7 +305,7 @@ def test_attention_online_softmax_rescale_spike(pkg, gpu):
     _attn_check(out, _attn_ref(q, k, v, heads), "rescale spike")
 
 
-def test_attention_large_scores_no_overflow(pkg, gpu):
+def test_attention_large_scores_no_overflow(pkg, gpu, att_body):
     heads, S = 2, 256
     q = rnd((1, S, heads * 128), gpu, 6.0, seed=36)
     k = rnd((1, S, heads * 128), gpu, 6.0, seed=37)
@@ -663,7 +672,7 @@ def test_gemm256_identity_asymmetric(pkg, gpu):
 
 # ------------------------------------------------------------------------------------------------ split-KV attention
 @pytest.mark.parametrize("heads,Sq,Sk,ns", [(2, 256, 2048, 2), (4, 300, 4100, 4), (32, 256, 4096, 8)])
-def test_attention_splitkv_matches_single_pass(pkg, gpu, heads, Sq, Sk, ns):
+def test_attention_splitkv_matches_single_pass(pkg, gpu, heads, Sq, Sk, ns, att_body):
     q = rnd((1, Sq, heads * 128), gpu, seed=60)
     k = rnd((1, Sk, heads * 128), gpu, seed=61)
     v = rnd((1, Sk, heads * 128), gpu, seed=62)
@@ -676,7 +685,7 @@ def test_attention_splitkv_matches_single_pass(pkg, gpu, heads, Sq, Sk, ns):
     assert (split.float() - one.float()).abs().max().item() < 0.02
 
 
-def test_attention_planned_tail_matches_single_pass(pkg, gpu):
+def test_attention_planned_tail_matches_single_pass(pkg, gpu, att_body):
     """Automatic plan at a band shape: 8 q-blocks unsplit + the 9th in key chunks (native.attention_plan)."""
     heads, Sq, Sk = 32, 2304, 4096
     assert len(pkg.native.attention_plan(1, heads, Sq, Sk)) == 2

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as G  # noqa: E402
 
 OUT = os.path.join(ROOT, "build", "variants")
-PER_FILE = {"attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+PER_FILE = {"attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"], "attention16.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 
 
 def main():

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
     ap.add_argument("--cold", type=int, default=1, help="gemm: rotate over this many copies of the weights (and activations) so that "
                     "they come from HBM, not from the 256 MB Infinity Cache, as inside the model (4-6 copies)")
+    ap.add_argument("--shapes", default="", help="attention: comma list of kernel bodies to time in one process (0 = 32x32x16, 1 = 16x16x32)")
     ap.add_argument("--diag", default="", help="attention: library built with -DATT_DIAG=1; prints the per-segment cycle shares")
     args = ap.parse_args()
     pkg = load_package()
@@ -67,7 +68,15 @@ def main():
             rc = lib.drn_attention_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, o.data_ptr(), 1, H, S, Sk,
                                         3 * D, 3 * D, 3 * D, D, 0, 0, 0, 0, 128 ** -0.5, st)
             assert rc == 0, rc
-        cases.append(("attention Sq=%d Sk=%d" % (S, Sk), run_attn, fl))
+        if args.shapes:
+            for sh in [int(v) for v in args.shapes.split(",")]:
+                def run_shape(lib, sh=sh):
+                    lib.drn_attention_force_shape16(sh)
+                    run_attn(lib)
+                    lib.drn_attention_force_shape16(-1)
+                cases.append(("attention Sq=%d Sk=%d body %s" % (S, Sk, ("32x32x16", "16x16x32")[sh]), run_shape, fl))
+        else:
+            cases.append(("attention Sq=%d Sk=%d" % (S, Sk), run_attn, fl))
     if "gemm" in args.what:
         a = rnd(S, D)
         for (Nn, K, epi, nm) in [(3 * D, D, 0, "qkv"), (D, D, 2, "out+gate"), (4 * D, D, 1, "mlp1+gelu"), (D, 4 * D, 2, "mlp2+gate")]:

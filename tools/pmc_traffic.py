@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILIES = {"gemm": ("gemm256s_kernel", "gemm256w_kernel", "gemm_tall_kernel", "gemm144_kernel", "gemm_bf16_kernel"), "attention": ("attention_fwd_kernel", "attention_combine_kernel"),
+FAMILIES = {"gemm": ("gemm256s_kernel", "gemm256w_kernel", "gemm_tall_kernel", "gemm144_kernel", "gemm_bf16_kernel"), "attention": ("attention16_fwd_kernel", "attention_fwd_kernel", "attention_combine_kernel"),
             "conv": ("conv_igemm_kernel", "conv256s_kernel")}
 
 
