@@ -187,6 +187,8 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
 #ifndef ATT16_DMA_IN_S
 #define ATT16_DMA_IN_S 0
 #endif
+// (tried and rejected, kbench A/B in one process: the four waves of a group requesting a piece at four different fragment steps
+//  instead of all at once: 4.33 -> 4.62 ms; the row sum by v_dot2c_f32_bf16 on the packed P: 4.32 -> 4.61 ms)
 // ATT16_ABL: timing-only ablations (results WRONG; shipped with 0): 1 = no exp (softmax VALU minus the 32 transcendentals),
 // 2 = no softmax at all (M segments alone), 4 = no K/V DMA inside the loop
 #ifndef ATT16_ABL
