@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
-TRAFFIC_PROFILE = "r02_pmc_traffic.json"
+TRAFFIC_PROFILE = "r03_pmc_traffic.json"
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 

@@ -140,7 +140,11 @@ class HipCosmosTokenizer:
             for f in range(T):                                        # one head of dim C per frame
                 s = V.dense_gemm(q[f], k[f].contiguous(), out_f32=True, alpha=scale)
                 p = V.softmax_rows(s, Pk, kp)
-                V.dense_gemm(p, V.transpose(v[f].contiguous(), kp), out=o[f])
+                vt = V.transpose(v[f].contiguous(), kp)
+                if kp % 64 == 0 and C % 128 == 0:
+                    N.gemm(p, vt, out=o[f])                           # P . V on the DiT's tile GEMM (bf16 out, fp32 accumulate)
+                else:
+                    V.dense_gemm(p, vt, out=o[f])
         oc = CL(T, H, W, C, 0, self.device, tensor=o.view(T, H, W, C))
         return self.conv(name + ".to_out.0", oc, residual=x)
 

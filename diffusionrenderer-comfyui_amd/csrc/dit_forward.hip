@@ -6,6 +6,7 @@
 // Why it exists: a forward is ~570 launches; through ctypes + torch wrappers each costs the host 6-12 us, which at S = 256
 // (cfg 1: a 6.8 ms GPU step) made the host the bound of the denoising loop.  From C the same launches cost the host ~2 ms.
 // Host code only (no kernel lives in this file).
+#include <stdlib.h>
 #include "drn_common.h"
 
 // ---- how to cover the (q-block, head) grid with whole rounds of the 256 CUs (was native.attention_plan; measured cost model)
@@ -141,15 +142,23 @@ struct Scope {                                           // event pair around on
         if (rc_ != DRN_OK) return rc_; \
     } while (0)
 
-// out = epi(A . W^T) exactly as native.gemm dispatches it: split-K for few-token products (decided from ONE clip's rows)
+// out = epi(A . W^T) exactly as native.gemm dispatches it: split-K for few-token products (decided from ONE clip's rows).
+// `defer`: a split-K product with the gated-residual epilogue may stop after its slices (returns *defer = split count): the
+// caller folds sum + epilogue into the next LayerNorm pass (drn_splitk_gate_res_ln_modulate: the same bits).
 static int fwd_gemm(const drn_dit_forward_args* a, const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K,
-                    int64_t lda, int64_t ldc, int epi, const void* gate, const void* residual, int64_t ldr, void* stream) {
+                    int64_t lda, int64_t ldc, int epi, const void* gate, const void* residual, int64_t ldr, void* stream,
+                    int* defer = nullptr) {
     const int64_t rpb = a->S;
     const int64_t Mb = (rpb > 0 && rpb < M && M % rpb == 0) ? rpb : M;
     const int splits = Mb <= 1024 ? drn_gemm_splitk_choice(Mb, N, K) : 1;
     Scope sc((drn_timer*)a->timer, 0, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N * (residual ? 2 : 1)), (hipStream_t)stream);
+    if (defer) *defer = 0;
     if (splits > 1) {
         if (!a->gemm_ws || drn_gemm_splitk_workspace_bytes(M, N, splits) > a->gemm_ws_bytes) return DRN_EINVAL;
+        if (defer && epi == DRN_EPI_GATE_RES && N == a->D && N > 1024 && ldc == N && ldr == N && residual == C) {
+            *defer = splits;
+            return drn_gemm_bf16_splitk_partials(A, W, M, N, K, lda, K, rpb, splits, a->gemm_ws, stream);
+        }
         return drn_gemm_bf16_splitk(A, W, C, M, N, K, lda, K, ldc, epi, gate, residual, ldr, rpb, splits, a->gemm_ws, stream);
     }
     return drn_gemm_bf16(A, W, C, M, N, K, lda, K, ldc, epi, gate, residual, ldr, rpb, stream);
@@ -194,6 +203,25 @@ extern "C" int drn_dit_forward(const drn_dit_forward_args* a, void* stream) {
     DRN_TRY(fwd_gemm(a, a->P, a->w_patch, a->X, M, D, a->kpad, a->kpad, D, DRN_EPI_NONE, nullptr, nullptr, 0, stream));
 
     const bf16_t* pending = nullptr;                     // the broadcast cross-attention residual not yet added to X
+    int deferred = 0;                                    // > 0: X still lacks sum(partials) + gate/residual of the last linear
+    const bf16_t* deferred_gate = nullptr;
+    static int fuse = -1;
+    if (fuse < 0) {
+        const char* e = getenv("DRN_FUSE_SPLITK_LN");    // 0: the split-K epilogue and the LayerNorm as two launches (A/B runs)
+        fuse = (e && e[0] == '0') ? 0 : 1;
+    }
+    // LayerNorm + modulate of X into H, folding a deferred split-K epilogue in
+#define LN_NEXT(SH, SC)                                                                                               \
+    do {                                                                                                              \
+        if (deferred) {                                                                                               \
+            DRN_TRY(drn_splitk_gate_res_ln_modulate(a->gemm_ws, deferred, a->X, deferred_gate, pending, SH, SC, a->H, M, D, S,  \
+                                                    a->eps, stream));                                                 \
+            deferred = 0;                                                                                             \
+        } else {                                                                                                      \
+            DRN_TRY(drn_ln_modulate(a->X, pending, SH, SC, a->H, M, D, S, a->eps, stream));                           \
+        }                                                                                                             \
+        pending = nullptr;                                                                                            \
+    } while (0)
     for (int i = 0; i < a->n_sub; ++i) {
         const drn_dit_sub* sb = &a->subs[i];
         const bf16_t* sh = shift + (int64_t)sb->site * a->shift_site_stride;
@@ -201,12 +229,19 @@ extern "C" int drn_dit_forward(const drn_dit_forward_args* a, void* stream) {
         const bf16_t* gt = gate + (int64_t)sb->site * a->gate_site_stride;
         if (sb->kind == DRN_SUB_CA) {
             DRN_CHECK_ARG(a->addvec && sb->ca_index >= 0);
-            if (pending) DRN_TRY(drn_bcast_add(a->X, pending, M, D, S, stream));
+            if (pending) {
+                // two cross-attention blocks in a row (not in FA-CA-MLP): X must be complete before the stand-alone add
+                if (deferred) {
+                    DRN_TRY(drn_splitk_gate_res_ln_modulate(a->gemm_ws, deferred, a->X, deferred_gate, nullptr, sh, sc, a->H, M, D, S,
+                                                            a->eps, stream));       // (H is scratch here)
+                    deferred = 0;
+                }
+                DRN_TRY(drn_bcast_add(a->X, pending, M, D, S, stream));
+            }
             pending = (const bf16_t*)a->addvec + (int64_t)sb->ca_index * a->addvec_stride;
             continue;
         }
-        DRN_TRY(drn_ln_modulate(a->X, pending, sh, sc, a->H, M, D, S, a->eps, stream));
-        pending = nullptr;
+        LN_NEXT(sh, sc);
         if (sb->kind == DRN_SUB_FA) {
             DRN_CHECK_ARG(sb->w_a && sb->w_b && sb->qn && sb->kn && a->cos && a->sin);
             bf16_t* q = (bf16_t*)a->QKV;
@@ -233,17 +268,21 @@ extern "C" int drn_dit_forward(const drn_dit_forward_args* a, void* stream) {
                     }
                 }
             }
-            DRN_TRY(fwd_gemm(a, a->O, sb->w_b, a->X, M, D, D, D, D, DRN_EPI_GATE_RES, gt, a->X, D, stream));
+            DRN_TRY(fwd_gemm(a, a->O, sb->w_b, a->X, M, D, D, D, D, DRN_EPI_GATE_RES, gt, a->X, D, stream, fuse ? &deferred : nullptr));
+            deferred_gate = gt;
         } else if (sb->kind == DRN_SUB_MLP) {
             DRN_CHECK_ARG(sb->w_a && sb->w_b);
             DRN_TRY(fwd_gemm(a, a->H, sb->w_a, a->U, M, a->hidden, D, D, a->hidden, DRN_EPI_GELU, nullptr, nullptr, 0, stream));
-            DRN_TRY(fwd_gemm(a, a->U, sb->w_b, a->X, M, D, a->hidden, a->hidden, D, DRN_EPI_GATE_RES, gt, a->X, D, stream));
+            DRN_TRY(fwd_gemm(a, a->U, sb->w_b, a->X, M, D, a->hidden, a->hidden, D, DRN_EPI_GATE_RES, gt, a->X, D, stream,
+                             fuse ? &deferred : nullptr));
+            deferred_gate = gt;
         } else {
             return DRN_EINVAL;
         }
     }
     // final layer (CleanGeneralDIT.py:583-590): LN + modulate with the first 2D of the LoRA vector, Linear(D -> n_final)
-    DRN_TRY(drn_ln_modulate(a->X, pending, a->final_shift, a->final_scale, a->H, M, D, S, a->eps, stream));
+    LN_NEXT((const bf16_t*)a->final_shift, (const bf16_t*)a->final_scale);
+#undef LN_NEXT
     DRN_TRY(fwd_gemm(a, a->H, a->w_final, a->Y, M, a->n_final, D, D, a->n_final, DRN_EPI_NONE, nullptr, nullptr, 0, stream));
     return DRN_OK;
 }

@@ -195,6 +195,128 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel4(bf16_t* __restrict__ 
     }
 }
 
+// Split-K sum + gated residual + the NEXT sub-block's LayerNorm / modulate in one pass (few-token shapes: cfg 1 ran
+// gemm_splitk_epilogue_kernel<2> and ln_modulate back to back on 2 MB of activations, ~9 us + ~6 us + a launch gap, 56 times per forward):
+//   a     = part[0][row] + part[1][row] + ...            fp32, slices in order        (= gemm_splitk_epilogue_kernel)
+//   x     = bf16(x + bf16(gate * bf16(a)))               written back                 (= its DRN_EPI_GATE_RES epilogue)
+//   x     = bf16(x + add_vec) if add_vec                 written back instead         (= ln_modulate's broadcast pre-add)
+//   h     = modulate(LayerNorm(x))                       four waves per row           (= ln_modulate_kernel4: same summation tree)
+// Every step rounds where the separate kernels round: the same bits as epilogue kernel + ln_modulate.
+template <int NCH>
+__global__ __launch_bounds__(256) void splitk_gate_res_ln_kernel(const float* __restrict__ part, int splits, int64_t part_stride,
+                                                                 bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
+                                                                 const bf16_t* __restrict__ add, const bf16_t* __restrict__ shift,
+                                                                 const bf16_t* __restrict__ scale, bf16_t* __restrict__ h,
+                                                                 int D, int64_t rpb, float eps) {
+    static_assert(NCH >= 4 && NCH % 4 == 0, "four waves per row");
+    constexpr int G = NCH / 4;
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t b = row / rpb;
+    bf16_t* xr = x + row * D;
+    const float* pr = part + row * D;
+    const bf16_t* gr = gate + b * D;
+    const bf16_t* ar = add ? add + b * D : nullptr;
+    const bf16_t* sh = shift + b * D;
+    const bf16_t* sc = scale + b * D;
+    float v[G][8], fs[G][8], fc[G][8];
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = (lane + 64 * (w * G + g)) * 8;
+        float s = 0.f;
+        if (c < D) {
+            f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(pr + c), a1 = *reinterpret_cast<const f32x4_t*>(pr + c + 4);
+            for (int sp = 1; sp < splits; ++sp) {
+                a0 += *reinterpret_cast<const f32x4_t*>(pr + sp * part_stride + c);
+                a1 += *reinterpret_cast<const f32x4_t*>(pr + sp * part_stride + c + 4);
+            }
+            float xv[8], gv[8];
+            unpack8(*reinterpret_cast<const uint4*>(xr + c), xv);
+            unpack8(*reinterpret_cast<const uint4*>(gr + c), gv);
+            unpack8(*reinterpret_cast<const uint4*>(sh + c), fs[g]);
+            unpack8(*reinterpret_cast<const uint4*>(sc + c), fc[g]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float acc = j < 4 ? a0[j] : a1[j - 4];
+                v[g][j] = rbf(xv[j] + rbf(gv[j] * rbf(acc)));
+            }
+            if (ar) {
+                float a[8];
+                unpack8(*reinterpret_cast<const uint4*>(ar + c), a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[g][j] = rbf(v[g][j] + a[j]);
+            }
+            *reinterpret_cast<uint4*>(xr + c) = pack8(v[g]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[g][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[g][j] = 0.f;
+        }
+        t += s;
+    }
+    t = wave_sum(t);
+    if (lane == 0) red[0][w] = t;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+    float tq = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = (lane + 64 * (w * G + g)) * 8;
+        float q = 0.f;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[g][j] - mean;
+                q += d * d;
+            }
+        }
+        tq += q;
+    }
+    tq = wave_sum(tq);
+    if (lane == 0) red[1][w] = tq;
+    __syncthreads();
+    const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    bf16_t* hr = h + row * D;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = (lane + 64 * (w * G + g)) * 8;
+        if (c < D) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = rbf((v[g][j] - mean) * rstd);
+                const float s1 = rbf(1.0f + fc[g][j]);
+                o[j] = rbf(rbf(n * s1) + fs[g][j]);
+            }
+            *reinterpret_cast<uint4*>(hr + c) = pack8(o);
+        }
+    }
+}
+
+extern "C" int drn_splitk_gate_res_ln_modulate(const void* partials, int splits, void* x, const void* gate, const void* add_vec,
+                                               const void* shift, const void* scale, void* h, int64_t rows, int64_t D,
+                                               int64_t rows_per_batch, float eps, void* stream) {
+    DRN_CHECK_ARG(partials && x && gate && shift && scale && h && splits >= 1 && rows >= 0 && rows < (1ll << 31));
+    DRN_CHECK_ARG(D > 1024 && D % 8 == 0 && D <= 8192 && rows_per_batch > 0 && ((uintptr_t)partials & 15) == 0);
+    if (rows == 0) return DRN_OK;
+    const int nch = (int)((D + 511) / 512);
+    dim3 grid((unsigned)rows), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(N)                                                                                                     \
+    splitk_gate_res_ln_kernel<N><<<grid, block, 0, st>>>((const float*)partials, splits, rows * D, (bf16_t*)x,       \
+        (const bf16_t*)gate, (const bf16_t*)add_vec, (const bf16_t*)shift, (const bf16_t*)scale, (bf16_t*)h, (int)D,  \
+        rows_per_batch, eps)
+    if (nch <= 4) LAUNCH(4);
+    else if (nch <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    return drn_launch_status();
+}
+
 static int g_ln_force = -1;      // tests: 0 = one wave per row always, 1 = four waves per row wherever it exists, -1 = by row count
 extern "C" void drn_ln_force_kernel(int which) { g_ln_force = which; }
 

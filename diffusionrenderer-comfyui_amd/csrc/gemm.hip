@@ -480,6 +480,36 @@ extern "C" int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
     return tiles <= 256 ? best : 1;
 }
 
+// the K slices of a split-K product: fp32 partials [splits][M][N] in `workspace`, nothing else (arguments validated by the callers)
+static int splitk_slices(const void* A, const void* W, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                         int64_t rows_per_batch, int splits, void* workspace, void* stream) {
+    const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
+    DRN_CHECK_ARG(tiles < 65536);
+    hipStream_t st = (hipStream_t)stream;
+    // which kernel computes the slices is a function of ONE clip's rows and the split count the caller got from
+    // drn_gemm_splitk_choice for those rows (batch-invariant results)
+    const int64_t Mb = (rows_per_batch > 0 && rows_per_batch < M && M % rows_per_batch == 0) ? rows_per_batch : M;
+    if (M % 256 == 0 && tall_choice(Mb, N, K) == splits)
+        return drn_gemm_tall_dispatch(A, W, workspace, (float*)workspace, M, N, K, lda, ldw, N, DRN_EPI_NONE, nullptr, nullptr, 0,
+                                      rows_per_batch, splits, stream);
+    if ((g_force_tile < 0 || g_force_tile == 4) && M % 256 == 0 && splitk256_choice(Mb, N, K) == splits)
+        return drn_gemm256s_partial(A, W, (float*)workspace, M, N, K, lda, ldw, splits, stream, g_force_tile != 4);
+    gemm_bf16_kernel<DRN_EPI_NONE><<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st>>>(
+        (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)workspace, M, N, K, lda, ldw, N, nullptr, nullptr, 0, 1, (float*)workspace);
+    return drn_launch_status();
+}
+
+// slices only: the caller sums them itself (drn_splitk_gate_res_ln_modulate folds the sum, the gated residual and the next
+// LayerNorm into one pass).  Same slices, bit for bit, as drn_gemm_bf16_splitk computes.
+extern "C" int drn_gemm_bf16_splitk_partials(const void* A, const void* W, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                             int64_t rows_per_batch, int splits, void* workspace, void* stream) {
+    DRN_CHECK_ARG(A && W && workspace && M > 0 && N > 0 && K > 0 && splits > 1 && splits <= 64);
+    DRN_CHECK_ARG(K % BK == 0 && N % BN == 0 && (K / BK) % splits == 0);
+    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K);
+    DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)workspace & 15) == 0);
+    return splitk_slices(A, W, M, N, K, lda, ldw, rows_per_batch, splits, workspace, stream);
+}
+
 extern "C" int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                     int64_t ldw, int64_t ldc, int epilogue, const void* gate, const void* residual,
                                     int64_t ldr, int64_t rows_per_batch, int splits, void* workspace, void* stream) {
@@ -492,23 +522,11 @@ extern "C" int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64
     if (epilogue == DRN_EPI_GATE_RES)
         DRN_CHECK_ARG(gate && residual && ldr % 8 == 0 && ldr >= N && rows_per_batch > 0 && ((uintptr_t)residual & 7) == 0);
     if (epilogue < DRN_EPI_NONE || epilogue > DRN_EPI_GATE_RES) return DRN_EINVAL;
-    const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
-    DRN_CHECK_ARG(tiles < 65536);
-    hipStream_t st = (hipStream_t)stream;
-    // which kernel computes the slices is a function of ONE clip's rows and the split count the caller got from
-    // drn_gemm_splitk_choice for those rows (batch-invariant results)
-    const int64_t Mb = (rows_per_batch > 0 && rows_per_batch < M && M % rows_per_batch == 0) ? rows_per_batch : M;
-    if (M % 256 == 0 && tall_choice(Mb, N, K) == splits) {
-        const int rc = drn_gemm_tall_dispatch(A, W, C, (float*)workspace, M, N, K, lda, ldw, ldc, epilogue, gate, residual, ldr,
-                                              rows_per_batch, splits, stream);
+    {
+        const int rc = splitk_slices(A, W, M, N, K, lda, ldw, rows_per_batch, splits, workspace, stream);
         if (rc != DRN_OK) return rc;
-    } else if ((g_force_tile < 0 || g_force_tile == 4) && M % 256 == 0 && splitk256_choice(Mb, N, K) == splits) {
-        const int rc = drn_gemm256s_partial(A, W, (float*)workspace, M, N, K, lda, ldw, splits, stream, g_force_tile != 4);
-        if (rc != DRN_OK) return rc;
-    } else {
-        gemm_bf16_kernel<DRN_EPI_NONE><<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st>>>(
-            (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, nullptr, nullptr, 0, 1, (float*)workspace);
     }
+    hipStream_t st = (hipStream_t)stream;
     int64_t blocks = (M * (N / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
 #define EARGS (const float*)workspace, splits, (bf16_t*)C, M, N, ldc, (const bf16_t*)gate, (const bf16_t*)residual, ldr, rows_per_batch

@@ -80,6 +80,9 @@ int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64_t M, int64
                          const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
                          int splits, void* workspace, void* stream);
 int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
+/* the K slices alone: fp32 partials [splits][M][N] in `workspace`, no sum, no epilogue (the same slices, bit for bit) */
+int drn_gemm_bf16_splitk_partials(const void* A, const void* W, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldw, int64_t rows_per_batch, int splits, void* workspace, void* stream);
 int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K);
 
 /* ---- tuning hooks of drn_gemm_bf16 (no reference counterpart): which tile kernel the wave-quantisation model picks for an
@@ -109,6 +112,14 @@ int drn_gemv_bf16(const void* x, const void* W, void* y, int64_t N, int64_t K,
  * x,h: [rows, D] bf16; shift/scale/add_vec: [batches, D] bf16; batch = row / rows_per_batch. D % 8 == 0, D <= 8192. */
 int drn_ln_modulate(void* x, const void* add_vec, const void* shift, const void* scale, void* h,
                     int64_t rows, int64_t D, int64_t rows_per_batch, float eps, void* stream);
+/* ---- the sum of split-K partials, the gated residual (CleanGeneralDIT.py:517) and the NEXT sub-block's LayerNorm + modulate
+ * (:481, :506) in one pass over [rows, D] (few-token shapes: drn_dit_forward uses it where a linear was split along K):
+ *   x <- bf16(x + bf16(gate * bf16(sum_s partials[s]))) [; x <- bf16(x + add_vec)];  h = modulate(LN(x)).
+ * Rounds exactly where drn_gemm_bf16_splitk(DRN_EPI_GATE_RES) followed by drn_ln_modulate rounds: the same bits.
+ * partials: fp32 [splits][rows][D]; gate / add_vec / shift / scale: [batches, D] bf16.  1024 < D <= 8192. */
+int drn_splitk_gate_res_ln_modulate(const void* partials, int splits, void* x, const void* gate, const void* add_vec,
+                                    const void* shift, const void* scale, void* h, int64_t rows, int64_t D,
+                                    int64_t rows_per_batch, float eps, void* stream);
 /* tuning hook (tests / A-B runs; no reference counterpart): the row statistics come from ONE summation tree that a
  * one-wave-per-row and a four-waves-per-row kernel share (same bits); -1 = chosen by row count, 0 / 1 force either. */
 void drn_ln_force_kernel(int which);

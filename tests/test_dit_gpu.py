@@ -193,11 +193,13 @@ def test_full_model_cfg3_batch_and_determinism(pkg, gpu, full28_dit):
 
 
 @pytest.mark.parametrize("D,L,heads,lat,B", [(256, 2, 2, (2, 16, 16), 1), (256, 2, 2, (2, 16, 16), 3), (512, 1, 4, (1, 32, 32), 2),
-                                               (1024, 1, 8, (2, 64, 64), 1)])
+                                               (1024, 1, 8, (2, 64, 64), 1), (2048, 2, 16, (1, 32, 32), 1), (2048, 1, 16, (1, 32, 32), 3)])
 def test_forward_sequencer_equals_per_launch_path(pkg, gpu, D, L, heads, lat, B):
     """drn_dit_forward (ONE C call enqueues patch embed, every sub-block and the final layer; the default on one GPU) against the
     per-launch host path (one ctypes call per kernel; what the traces of the golden tests above and the sharded engine run):
-    same kernels, same arguments, same order -> the same bits.  S = 128 / 256 (split-K GEMMs + workspaces) and 2048."""
+    same kernels, same arguments, same order -> the same bits.  S = 128 / 256 (split-K GEMMs + workspaces) and 2048; at D = 2048
+    the sequencer folds the split-K sum + gated residual of the out-projection / MLP-down into the next LayerNorm pass
+    (drn_splitk_gate_res_ln_modulate) where the per-launch path runs epilogue kernel and LayerNorm one after the other."""
     net = tiny_net(pkg, D, L, heads)
     sw = pkg.synthetic_weights
     sd = sw.synth_state_dict(net, torch.bfloat16, device=gpu)
