@@ -140,6 +140,11 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x4_t lacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};       // ATT16_LSUM_MFMA: ones . P^T (every row = the row sum)
+    bf16x8_t ones_frag;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones_frag[i] = (short)0x3f80;
+    asm volatile("" : "+v"(ones_frag));                              // (a register operand, not eight literals per MFMA)
     f32x4_t sacc[4][2];
     bf16x8_t pb[2][2] = {};
 
@@ -189,6 +194,13 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
 #endif
 // (tried and rejected, kbench A/B in one process: the four waves of a group requesting a piece at four different fragment steps
 //  instead of all at once: 4.33 -> 4.62 ms; the row sum by v_dot2c_f32_bf16 on the packed P: 4.32 -> 4.61 ms)
+// ATT16_LSUM_MFMA 1: the softmax denominator comes off the matrix pipe - one extra MFMA per key step and query tile multiplies the
+// bf16 P^T fragment by a fragment of ones (no LDS read), instead of 32 v_add_f32 per tile in the softmax segment, which is the
+// longer of the two segments in this body; the sum is then that of the ROUNDED probabilities the PV product uses, and every lane of
+// a query holds it (no cross-lane step in the epilogue).
+#ifndef ATT16_LSUM_MFMA
+#define ATT16_LSUM_MFMA 1
+#endif
 // ATT16_ABL: timing-only ablations (results WRONG; shipped with 0): 1 = no exp (softmax VALU minus the 32 transcendentals),
 // 2 = no softmax at all (M segments alone), 4 = no K/V DMA inside the loop
 #ifndef ATT16_ABL
@@ -204,6 +216,10 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
             const bf16x8_t vf_ = JOIN(vring[(F) & 7]);                                        \
             acc[(F) & 7][0] = MFMA16(vf_, pb[(F) >> 3][0], acc[(F) & 7][0]);                  \
             acc[(F) & 7][1] = MFMA16(vf_, pb[(F) >> 3][1], acc[(F) & 7][1]);                  \
+            if (ATT16_LSUM_MFMA && ((F) & 7) == 4) {       /* row sums of key step s (any step of it would do) */ \
+                lacc[0] = MFMA16(ones_frag, pb[(F) >> 3][0], lacc[0]);                        \
+                lacc[1] = MFMA16(ones_frag, pb[(F) >> 3][1], lacc[1]);                        \
+            }                                                                                 \
         }                                                                                     \
         if (NEXT) ISSUE((F) + 8);                                                             \
         FENCE();                                                                              \
@@ -274,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
                 m_thr[qt] = m_new + thr_raw;                                                  \
                 mcs[qt] = m_new * scale_log2e;                                                \
                 l_run[qt] *= alpha;                                                           \
+                lacc[qt] *= alpha;                                                            \
                 _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) acc[dt][qt] *= alpha;        \
             }                                                                                 \
         }                                                                                     \
@@ -285,13 +302,13 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                               \
                     if (ATT16_ABL & 1) p[j] = sacc[2 * s_ + (j >> 2)][qt][j & 3] * scale_log2e - mc;      \
                     else p[j] = __builtin_amdgcn_exp2f(sacc[2 * s_ + (j >> 2)][qt][j & 3] * scale_log2e - mc); \
-                    ps[j & 1] += p[j];                                                        \
+                    if (!ATT16_LSUM_MFMA) ps[j & 1] += p[j];                                  \
                 }                                                                             \
                 union { bf16x8_t v; uint32_t u[4]; } cv;                                      \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) cv.u[i] = pack_bf2(p[2 * i], p[2 * i + 1]); \
                 pb[s_][qt] = cv.v;                                                            \
             }                                                                                 \
-            l_run[qt] += ps[0] + ps[1];                                                       \
+            if (!ATT16_LSUM_MFMA) l_run[qt] += ps[0] + ps[1];                                 \
         }                                                                                     \
     } while (0)
 
@@ -404,8 +421,12 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
     float l_tot[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = l_run[qt] + __shfl_xor(l_run[qt], 16, 64);
-        l_tot[qt] = l + __shfl_xor(l, 32, 64);
+        if (ATT16_LSUM_MFMA) {
+            l_tot[qt] = lacc[qt][0];
+        } else {
+            float l = l_run[qt] + __shfl_xor(l_run[qt], 16, 64);
+            l_tot[qt] = l + __shfl_xor(l, 32, 64);
+        }
     }
     if (nsplit > 1) {
         const int nbatch = total / (nqb * heads * nsplit);
