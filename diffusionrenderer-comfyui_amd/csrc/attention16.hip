@@ -201,6 +201,13 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
 #ifndef ATT16_LSUM_MFMA
 #define ATT16_LSUM_MFMA 1
 #endif
+// ATT16_PRIO: s_setprio of the M segment (default 1: its MFMAs win the issue arbitration against the partner's softmax); S runs at 0
+#ifndef ATT16_PRIO
+#define ATT16_PRIO 1
+#endif
+#ifndef ATT16_SPRIO
+#define ATT16_SPRIO 0
+#endif
 // ATT16_ABL: timing-only ablations (results WRONG; shipped with 0): 1 = no exp (softmax VALU minus the 32 transcendentals),
 // 2 = no softmax at all (M segments alone), 4 = no K/V DMA inside the loop
 #ifndef ATT16_ABL
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
         QK_MASK(T);                                                                           \
         if (!ATT16_DMA_IN_S) AFTER_REQUESTS(T);                                               \
         FENCE();                                                                              \
-        __builtin_amdgcn_s_setprio(0);                                                        \
+        __builtin_amdgcn_s_setprio(ATT16_SPRIO);                                              \
         /* tile T+1 has landed: only this segment's pieces of tile T+2 are younger (requests in S: nothing is younger) */ \
         if (ATT16_DMA_IN_S) DMA_WAIT(0); else DMA_WAIT(4);                                    \
         BARRIER();                                                                            \
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
     } while (0)
 
     // ---- tile 0: M(0) = QK(0) only.  va points at V[0] from the start (M(0)'s steps 24..31 read V[0]'s first key step)
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(ATT16_PRIO);
     ISSUE(16); ISSUE(17); ISSUE(18); ISSUE(19); ISSUE(20); ISSUE(21); ISSUE(22); ISSUE(23);
     FENCE();
     REQ_PIECE(0);
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
     M_QK(0);
     S_SEGMENT(0);
     for (int t = 1; t < nt; ++t) {
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(ATT16_PRIO);
         // PV(t-1): key step 0 (fragments 0..7, read at the end of M(t-1)) and key step 1 (8..15, requested here) of V[t-1]
         STEP_PV(0, PEND(0), 1); STEP_PV(1, PEND(1), 1); STEP_PV(2, PEND(2), 1); STEP_PV(3, PEND(3), 1);
         REQ_PIECE(0);
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
         S_SEGMENT(t);
     }
     // ---- M(nt) = PV(nt-1): nothing to request beyond fragment 15
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(ATT16_PRIO);
     STEP_PV(0, 14, 1); STEP_PV(1, 14, 1); STEP_PV(2, 14, 1); STEP_PV(3, 14, 1);
     STEP_PV(4, 14, 1); STEP_PV(5, 14, 1); STEP_PV(6, 14, 1); STEP_PV(7, 14, 1);
     STEP_PV(8, 14, 0); STEP_PV(9, 12, 0); STEP_PV(10, 10, 0); STEP_PV(11, 8, 0);
