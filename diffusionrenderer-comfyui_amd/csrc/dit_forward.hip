@@ -188,6 +188,9 @@ extern "C" int64_t drn_dit_forward_gemm_workspace_bytes(int64_t B, int64_t S, in
     return need;
 }
 
+extern "C" int64_t drn_dit_forward_args_bytes(void) { return (int64_t)sizeof(drn_dit_forward_args); }
+extern "C" int64_t drn_dit_sub_bytes(void) { return (int64_t)sizeof(drn_dit_sub); }
+
 extern "C" int drn_dit_forward(const drn_dit_forward_args* a, void* stream) {
     DRN_CHECK_ARG(a && a->struct_bytes == (int64_t)sizeof(drn_dit_forward_args));
     DRN_CHECK_ARG(a->S > 0 && a->B > 0 && a->D > 0 && a->heads > 0 && a->D == (int64_t)a->heads * 128 && a->hidden > 0);

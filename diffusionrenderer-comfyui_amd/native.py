@@ -42,6 +42,8 @@ class DitForwardArgs(Structure):              # drn_dit_forward_args (include/dr
 SIGNATURES = {
     "drn_attention_plan": [_I, _L, _L, POINTER(c_int64)],
     "drn_dit_forward": [POINTER(DitForwardArgs), _P],
+    "drn_dit_forward_args_bytes": [],
+    "drn_dit_sub_bytes": [],
     "drn_dit_forward_gemm_workspace_bytes": [_L, _L, _L, _L, _L, _L],
     "drn_dit_forward_attn_workspace_bytes": [_L, _I, _L],
     "drn_timer_create": [_I, _I],
@@ -80,7 +82,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"drn_error_string": c_char_p, "drn_attention_splitkv_workspace_bytes": c_int64,
              "drn_gemm_splitk_workspace_bytes": c_int64, "drn_dit_forward_gemm_workspace_bytes": c_int64,
-             "drn_dit_forward_attn_workspace_bytes": c_int64, "drn_timer_create": c_void_p, "drn_timer_destroy": None,
+             "drn_dit_forward_attn_workspace_bytes": c_int64, "drn_dit_forward_args_bytes": c_int64, "drn_dit_sub_bytes": c_int64, "drn_timer_create": c_void_p, "drn_timer_destroy": None,
              "drn_ln_force_kernel": None, "drn_attention_force_shape16": None}
 
 
@@ -104,6 +106,8 @@ def load_library():
         fn.restype = _RESTYPES.get(name, c_int)
     if lib.drn_abi_version() != 1:
         raise RuntimeError("libdrn.so ABI version mismatch")
+    if lib.drn_dit_forward_args_bytes() != ctypes.sizeof(DitForwardArgs) or lib.drn_dit_sub_bytes() != ctypes.sizeof(DitSub):
+        raise RuntimeError("libdrn.so: drn_dit_forward_args / drn_dit_sub layout differs from the ctypes mirror in native.py")
     _LIB = lib
     return lib
 

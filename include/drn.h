@@ -214,6 +214,8 @@ typedef struct drn_dit_forward_args {
     float eps; int32_t reserved;
 } drn_dit_forward_args;
 int drn_dit_forward(const drn_dit_forward_args* args, void* stream);
+int64_t drn_dit_forward_args_bytes(void);     /* sizeof the two structs as this library was compiled (binding self-check) */
+int64_t drn_dit_sub_bytes(void);
 int64_t drn_dit_forward_gemm_workspace_bytes(int64_t B, int64_t S, int64_t D, int64_t hidden, int64_t n_final, int64_t kpad);
 int64_t drn_dit_forward_attn_workspace_bytes(int64_t B, int heads, int64_t S);
 

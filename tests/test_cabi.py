@@ -42,3 +42,20 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     monkeypatch.setattr(pkg.native, "_LIB_NAME", "libdrn_missing.so")
     with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
         pkg.native.load_library()
+
+
+def test_struct_mirrors_match_the_library(pkg):
+    """native.DitForwardArgs / DitSub are field-for-field mirrors of drn_dit_forward_args / drn_dit_sub: same size as compiled,
+    and the attention plan / workspace helpers are host-only (callable without a GPU)."""
+    import ctypes
+    N = pkg.native
+    lib = N.load_library()
+    assert lib.drn_dit_forward_args_bytes() == ctypes.sizeof(N.DitForwardArgs)
+    assert lib.drn_dit_sub_bytes() == ctypes.sizeof(N.DitSub)
+    assert N.attention_plan(1, 32, 18432, 18432) == [(0, 18432, 1)]
+    assert lib.drn_dit_forward_attn_workspace_bytes(1, 32, 18432) == 0
+    # cfg 1: split-K partials of the widest few-token product (MLP-down, 16 slices of [256, 4096] fp32) fit the workspace
+    assert lib.drn_dit_forward_gemm_workspace_bytes(1, 256, 4096, 16384, 128, 192) >= 16 * 256 * 4096 * 4
+    a = N.DitForwardArgs()
+    a.struct_bytes = ctypes.sizeof(N.DitForwardArgs) - 8
+    assert lib.drn_dit_forward(ctypes.byref(a), None) == -1          # DRN_EINVAL before anything is launched

@@ -47,8 +47,13 @@ __device__ __forceinline__ float valu_block(float (&s)[32], float mc, float sc) 
     return sum + __uint_as_float(pk & 0x007fffffu);
 }
 
-template <int SHAPE, int MODE>   // MODE 1: MFMA waves only, 2: VALU waves only, 3: both
-__global__ __launch_bounds__(512, 2) void port_kernel(unsigned long long* out, float* sink, int iters) {
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int SHAPE, int MODE>   // MODE bit 0: MFMA waves run, bit 1: VALU waves run, bits 2..: LDS-DMA pieces (1 KiB) per MFMA segment
+__global__ __launch_bounds__(512, 2) void port_kernel(unsigned long long* out, float* sink, int iters, const char* src) {
+    __shared__ __attribute__((aligned(1024))) char lds[64 * 1024];
+    constexpr int PIECES = MODE >> 2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     unsigned long long t0 = 0, t1 = 0;
@@ -62,10 +67,30 @@ __global__ __launch_bounds__(512, 2) void port_kernel(unsigned long long* out, f
             f32x4_t acc16[16] = {};
             __builtin_amdgcn_s_setprio(1);
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+            const uint32_t voff = (uint32_t)(lane * 16 + wave * 4096);
             for (int it = 0; it < iters; ++it) {
-                mfma_segment<SHAPE>(acc32, acc16, a, b);
+                if (PIECES == 0) {
+                    mfma_segment<SHAPE>(acc32, acc16, a, b);
+                } else {
+                    // the segment in PIECES parts, one 1 KiB global -> LDS DMA (L2-resident source) after each part
+#pragma unroll
+                    for (int p = 0; p < PIECES; ++p) {
+                        if (SHAPE == 0) {
+#pragma unroll
+                            for (int i = 0; i < 32 / PIECES; ++i) acc32[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc32[i & 3], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 64 / PIECES; ++i) acc16[i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc16[i & 15], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_global_load_lds((gptr_t)(src + voff + ((it * PIECES + p) & 15) * 16384), (lptr_t)(lds + wave * 8192 + p * 1024), 16, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
                 asm volatile("" : "+v"(a), "+v"(b));
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -84,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void port_kernel(unsigned long long* out, f
         }
     }
     if (lane == 0) out[(size_t)blockIdx.x * 8 + wave] = t1 - t0;
-    if (res == 123.456f) sink[threadIdx.x] = res;
+    if (res == 123.456f) sink[threadIdx.x] = res + lds[threadIdx.x];
 }
 
 template <int SHAPE, int MODE>
@@ -92,13 +117,16 @@ static void run(const char* name, int iters) {
     const int blocks = 256;
     unsigned long long* d;
     float* sink;
+    char* src;
     hipMalloc(&d, blocks * 8 * sizeof(unsigned long long));
     hipMalloc(&sink, 512 * sizeof(float));
-    for (int rep = 0; rep < 3; ++rep) port_kernel<SHAPE, MODE><<<blocks, 512>>>(d, sink, iters);
+    hipMalloc(&src, 1 << 20);
+    hipMemset(src, 1, 1 << 20);
+    for (int rep = 0; rep < 3; ++rep) port_kernel<SHAPE, MODE><<<blocks, 512>>>(d, sink, iters, src);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int rep = 0; rep < 5; ++rep) port_kernel<SHAPE, MODE><<<blocks, 512>>>(d, sink, iters);
+    for (int rep = 0; rep < 5; ++rep) port_kernel<SHAPE, MODE><<<blocks, 512>>>(d, sink, iters, src);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
@@ -111,7 +139,7 @@ static void run(const char* name, int iters) {
     std::sort(m.begin(), m.end());
     std::sort(v.begin(), v.end());
     printf("%-34s MFMA segment %7.0f cycles   VALU block %7.0f cycles   kernel %.3f ms per launch\n", name, m[m.size() / 2], v[v.size() / 2], ms / 5);
-    hipFree(d); hipFree(sink);
+    hipFree(d); hipFree(sink); hipFree(src);
 }
 
 int main() {
@@ -121,5 +149,12 @@ int main() {
     run<0, 2>("VALU waves alone", iters);
     run<0, 3>("32x32x16 beside the VALU block", iters);
     run<1, 3>("16x16x32 beside the VALU block", iters);
+    // 4 (as the attention's M segment) and 8 (as a GEMM K step per wave) LDS-DMA pieces inside the MFMA segment
+    run<0, 1 + 16>("32x32x16 + 4 DMA pieces, alone", iters);
+    run<1, 1 + 16>("16x16x32 + 4 DMA pieces, alone", iters);
+    run<0, 3 + 16>("32x32x16 + 4 DMA pieces | VALU block", iters);
+    run<1, 3 + 16>("16x16x32 + 4 DMA pieces | VALU block", iters);
+    run<1, 1 + 32>("16x16x32 + 8 DMA pieces, alone", iters);
+    run<1, 3 + 32>("16x16x32 + 8 DMA pieces | VALU block", iters);
     return 0;
 }
