@@ -177,3 +177,49 @@ def test_shard_plan_rejects_uneven_split(pkg):
         pkg.parallel.ShardPlan(10, 0, 3)
     p = pkg.parallel.ShardPlan(18432, 5, 8)
     assert (p.rows, p.start, p.stop) == (2304, 11520, 13824)
+
+
+def _bands_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+        par = load_package().parallel
+        n, C = 5, 3
+        snd = (torch.arange(world * n * C, dtype=torch.float32).view(world, n, C) + 1000.0 * rank).to(torch.bfloat16)
+        whole = torch.empty_like(snd)
+        par.alltoall_rows_(snd, whole, dist.group.WORLD)
+        ok = all(bool((whole[r] == (torch.arange(n * C, dtype=torch.float32).view(n, C) + rank * n * C + 1000.0 * r).to(torch.bfloat16)).all())
+                 for r in range(world))
+        for cut in range(world + 1):                     # every way of sending the first `cut` destination bands early
+            got = torch.full_like(snd, -7.0)
+            works = [par.alltoall_bands_(snd, got, 0, cut, dist.group.WORLD, async_op=True),
+                     par.alltoall_bands_(snd, got, cut, world, dist.group.WORLD, async_op=True)]
+            for w in works:
+                if w is not None:
+                    w.wait()
+            ok = ok and torch.equal(got, whole)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_return_exchange_in_two_parts_equals_one_all_to_all(world):
+    """parallel.alltoall_bands_ at the world sizes the driver runs (4, 8): for every cut, the bands [0, cut) and [cut, world) sent as
+    two uneven all-to-alls deliver exactly what the one equal-split all-to-all delivers."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bands_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    for rank, ok in sorted(q.get(timeout=10) for _ in range(world)):
+        assert ok, f"rank {rank}"

@@ -85,9 +85,9 @@ def _worker(rank, world, port, q, exchange, wide=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,wide", [("a2a", False), ("gather", False), ("a2a", True), ("a2a", "clip")])
-def test_sharded_hipdit_equals_single_rank(gpu, exchange, wide):
-    world = 2
+@pytest.mark.parametrize("exchange,wide,world", [("a2a", False, 2), ("gather", False, 2), ("a2a", True, 2), ("a2a", "clip", 2),
+                                                 ("a2a", True, 4), ("gather", False, 4)])
+def test_sharded_hipdit_equals_single_rank(gpu, exchange, wide, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
