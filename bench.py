@@ -263,18 +263,30 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_run:
         return dry_run(args, world, rank)
+    # DRN_BENCH_BACKEND=gloo (rehearsal only, tests/test_parallel_gpu.py): the N ranks share THIS box's one GPU and exchange through
+    # gloo's host staging - every line of the N > 1 path below runs (sharded engine, exchange timers, max-over-ranks timing, JSON
+    # fields) except the RCCL transport itself.  The line is marked "transport": "gloo (rehearsal)" and is not a measurement.
+    backend = os.environ.get("DRN_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("DRN_BENCH_BACKEND must be nccl or gloo")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1 or "WORLD_SIZE" in os.environ:          # under torch.distributed.run (also its 1-rank rehearsal)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
-        # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step
         probe = torch.zeros(world * 1024, dtype=torch.bfloat16, device=dev)
-        dist.all_gather_into_tensor(torch.empty(world * 1024, dtype=torch.bfloat16, device=dev), probe[:1024].contiguous())
-        torch.cuda.synchronize()
-        if os.environ.get("DRN_SP_EXCHANGE", "auto") != "gather":
+        if backend == "nccl":
+            # bring the RCCL communicator (rings / xGMI peer mappings) up before any timed or warm-up step
+            dist.all_gather_into_tensor(torch.empty(world * 1024, dtype=torch.bfloat16, device=dev), probe[:1024].contiguous())
+            torch.cuda.synchronize()
+        if backend == "nccl" and os.environ.get("DRN_SP_EXCHANGE", "auto") != "gather":
             # the exchange this run will use, tried once before anything is timed.  If this RCCL build cannot run it the
             # process group is NOT reused (a communicator is unreliable after a failed collective): every rank that sees
             # the failure exits with PROBE_FAILED_RC and the launcher starts a fresh run with the all-gather exchange
@@ -357,7 +369,7 @@ def main():
     N.set_timer(None)
     pkg.parallel.set_exchange_timer(None)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = tmax.item()
     assert torch.isfinite(xt.float()).all(), "non-finite latent"
@@ -520,6 +532,7 @@ def main():
             "metric": "denoising_steps_per_sec", "value": round(steps_s, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "rccl_ranks": world,
+            **({"transport": "gloo (rehearsal: ranks share one GPU, host-staged exchanges - not a measurement)"} if backend == "gloo" else {}),
             "host_enqueue_ms_empty_queue": round(host_empty_ms, 2),
             "host_loop_wall_ms_per_step": round(1e3 * host_loop / args.steps, 2),
             "config": {"workload": f"inverse pass, {args.frames}f x {args.height} x {args.width} clip: EDM Euler step = 1 DiT "

@@ -277,3 +277,28 @@ def test_bench_under_torchrun_one_rank_rccl(gpu, exchange):
     want = {"a2a": {"a2a k|v", "a2a q", "a2a o (return)"}, "gather": {"gather k|v"}}[exchange]
     assert ex["kind"] == exchange and set(ex["exposed_ms_per_layer"]) == want, ex
     print(exchange, ex)
+
+
+@pytest.mark.parametrize("exchange", ["a2a", "gather"])
+def test_bench_two_ranks_rehearsal_over_gloo(gpu, exchange):
+    """`python bench.py --gpus 2` exactly as the driver calls it (self-launching: child torch.distributed.run, two ranks), with
+    DRN_BENCH_BACKEND=gloo so that both ranks can share this box's one GPU: the whole N > 1 path of bench.py runs - token-band
+    sharded engine at the headline clip's shapes (2 of the 28 blocks), the return all-to-all in two parts, barrier + max-over-ranks
+    timing, rank 0's single JSON line - only the transport is host-staged gloo instead of RCCL over xGMI."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DRN_SP_EXCHANGE=exchange, DRN_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--blocks", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-tokenizer", "--no-cfg"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert "gloo" in rec["transport"] and "exchange_fallback" not in rec
+    assert rec["config"]["tokens"] == 18432 and ("all-to-all" if exchange == "a2a" else "all-gather") in rec["config"]["parallelism"]
+    print(exchange, rec["ms_per_step"], rec["config"]["parallelism"])
