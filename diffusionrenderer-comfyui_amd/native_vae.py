@@ -60,17 +60,19 @@ class CL:
 
     __slots__ = ("t", "T", "H", "W", "C", "halo", "_key")
 
-    def __init__(self, T, H, W, C, halo=1, device=None, tensor=None):
+    def __init__(self, T, H, W, C, halo=1, device=None, tensor=None, live=None):
+        """live: how many of the C stored channels the producing kernel writes (16-channel latents live in 64-channel buffers
+        whose tail must stay zero): buffers are only recycled between activations with the same zero regions."""
         self.T, self.H, self.W, self.C, self.halo = T, H, W, C, halo
         self._key = None
         if tensor is None:
             shape = (T, H + 2 * halo, W + 2 * halo, C)
             if halo and _POOL_ON[0]:
-                key = (shape, torch.device(device) if device is not None else None)
+                key = (shape, C if live is None else int(live), torch.device(device) if device is not None else None)
                 free = _POOL.get(key)
                 tensor = free.pop() if free else torch.zeros(shape, dtype=BF, device=device)
                 self._key = key
-            elif halo:
+            elif halo or (live is not None and live < C):
                 tensor = torch.zeros(shape, dtype=BF, device=device)
             else:
                 tensor = torch.empty(shape, dtype=BF, device=device)      # no halo: every element is written
@@ -103,7 +105,7 @@ def conv3d(x: CL, w, bias, N_out, k, stride=(1, 1, 1), pad=0, t_off=None, out: C
     else:
         To, Ho, Wo = out_dims
     if out is None:
-        out = CL(To, Ho, Wo, out_channels_stored or N_out, out_halo, x.t.device)
+        out = CL(To, Ho, Wo, out_channels_stored or N_out, out_halo, x.t.device, live=N_out)
     assert (out.T, out.H, out.W) == (To, Ho, Wo) and out.C >= N_out
     assert w.shape == (N_out, kT * kH * kW * x.C), (w.shape, N_out, k, x.C)
     if residual is not None:
@@ -230,7 +232,7 @@ def temporal_attention(q, k, v, scale):
 
 def planar_to_cl(x, Cs, halo=1) -> CL:
     C, T, H, W = x.shape
-    out = CL(T, H, W, Cs, halo, x.device)
+    out = CL(T, H, W, Cs, halo, x.device, live=C)
     N._check(N.load_library().drn_planar_to_cl(x.contiguous().data_ptr(), out.t.data_ptr(), C, T, H, W, Cs, halo, N._stream()),
              "drn_planar_to_cl")
     return out
