@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
 #define ATT16_SPRIO 0
 #endif
 // ATT16_ABL: timing-only ablations (results WRONG; shipped with 0): 1 = no exp (softmax VALU minus the 32 transcendentals),
-// 2 = no softmax at all (M segments alone), 4 = no K/V DMA inside the loop
+// 2 = no softmax at all (M segments alone), 4 = no K/V DMA inside the loop, 8 = every DMA request re-reads tile 2 (always cached)
 #ifndef ATT16_ABL
 #define ATT16_ABL 0
 #endif
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
         kreq = kreq == NKB - 1 ? 0 : kreq + 1;                                                \
         vreq = vreq == NVB - 1 ? 0 : vreq + 1;                                                \
         if ((T) + 3 == nt - 1 && last_rows < KVT) CLAMP_LAST_TILE();    /* before the last tile is requested */ \
-        if ((T) + 3 <= nt - 1) { kreq_p += ktile_bytes; vreq_p += vtile_bytes; }              \
+        if (!(ATT16_ABL & 8) && (T) + 3 <= nt - 1) { kreq_p += ktile_bytes; vreq_p += vtile_bytes; }   /* (ABL 8: every request re-reads tile 2: cache hits) */ \
     } while (0)
     // QK(t) = steps 16..31 (+ the end of M(t)): K addresses move on to K[t+1] once the last K fragment is requested (step 23)
 #define M_QK(T)                                                                               \
