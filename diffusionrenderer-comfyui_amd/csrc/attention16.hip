@@ -208,6 +208,11 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
 #ifndef ATT16_SPRIO
 #define ATT16_SPRIO 0
 #endif
+// ATT16_BAR1 1: one barrier per tile (G0: M S |, G1: S M |) instead of one after every segment (LDS-safe on the 3 + 4 tile rings);
+// measured 4.236 -> 4.269 ms: not the lever
+#ifndef ATT16_BAR1
+#define ATT16_BAR1 0
+#endif
 // ATT16_ABL: timing-only ablations (results WRONG; shipped with 0): 1 = no exp (softmax VALU minus the 32 transcendentals),
 // 2 = no softmax at all (M segments alone), 4 = no K/V DMA inside the loop, 8 = every DMA request re-reads tile 2 (always cached)
 #ifndef ATT16_ABL
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
     DMA_WAIT(0);
     BARRIER();
     if (nt == 3 && last_rows < KVT) CLAMP_LAST_TILE();                // M(0) requests tile 2
-    if (grp == 1) BARRIER();                                          // G1 runs one interval behind G0
+    if (!ATT16_BAR1 && grp == 1) BARRIER();                           // G1 runs one interval behind G0
     const char* kreq_p = reinterpret_cast<const char*>(Kb) + (int64_t)min(2, nt - 1) * ktile_bytes;   // tile that M(0) requests
     const char* vreq_p = reinterpret_cast<const char*>(Vb) + (int64_t)min(2, nt - 1) * vtile_bytes;
     int kbuf = 0, vbuf = 0;                        // t % NKB, (t - 1) % NVB: the buffers ka / va point at
@@ -375,8 +380,10 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
         FENCE();                                                                              \
         __builtin_amdgcn_s_setprio(ATT16_SPRIO);                                              \
         /* tile T+1 has landed: only this segment's pieces of tile T+2 are younger (requests in S: nothing is younger) */ \
-        if (ATT16_DMA_IN_S) DMA_WAIT(0); else DMA_WAIT(4);                                    \
-        BARRIER();                                                                            \
+        if (!ATT16_BAR1 || grp == 1) {                                                        \
+            if (ATT16_DMA_IN_S) DMA_WAIT(0); else DMA_WAIT(4);                                \
+            BARRIER();                                                                        \
+        }                                                                                     \
     } while (0)
 #define S_SEGMENT(T)                                                                          \
     do {                                                                                      \
@@ -389,7 +396,8 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
         FENCE();                                                                              \
         /* the softmax is complete HERE (a conditional block behind it must not pull half of it down) */ \
         asm volatile("" : "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]), "+v"(l_run[0]), "+v"(l_run[1]) :: "memory"); \
-        BARRIER();                                                                            \
+        if (!ATT16_BAR1) BARRIER();                                                           \
+        else if (grp == 0) { DMA_WAIT(4); BARRIER(); }                                        \
     } while (0)
 
     // ---- tile 0: M(0) = QK(0) only.  va points at V[0] from the start (M(0)'s steps 24..31 read V[0]'s first key step)
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void attention16_fwd_kernel(
     STEP_PV(12, 6, 0); STEP_PV(13, 4, 0); STEP_PV(14, 2, 0); STEP_PV(15, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     DMA_WAIT(0);                                   // (the clamped re-requests of the last tile: nothing may land after the epilogue took the LDS)
-    if (grp == 0) BARRIER();                       // balance G1's extra barrier
+    if (!ATT16_BAR1 && grp == 0) BARRIER();        // balance G1's extra barrier
 
     // ---- epilogue: O[q][head*128 + d] = O^T[d][q] / l   (or the un-normalised partial when the keys are split)
     float l_tot[2];
