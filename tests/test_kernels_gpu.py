@@ -168,6 +168,36 @@ def test_ln_modulate_four_waves_per_row_equals_one_wave_per_row(pkg, gpu, rows, 
     assert ok, msg
 
 
+@pytest.mark.parametrize("rows,D,K,with_add", [(256, 4096, 4096, True), (256, 4096, 16384, False), (512, 2048, 2048, True), (256, 8192, 2048, False)])
+def test_splitk_sum_gated_residual_layernorm_in_one_pass(pkg, gpu, rows, D, K, with_add):
+    """drn_gemm_bf16_splitk_partials + drn_splitk_gate_res_ln_modulate (what drn_dit_forward runs for few-token linears) against
+    drn_gemm_bf16_splitk(DRN_EPI_GATE_RES) followed by drn_ln_modulate: X and H bit for bit."""
+    import ctypes
+    N = pkg.native
+    lib = N.load_library()
+    a, w = rnd((rows, K), gpu, seed=180), rnd((D, K), gpu, K ** -0.5, seed=181)
+    x0, gate = rnd((rows, D), gpu, seed=182), rnd((1, D), gpu, 0.5, seed=183)
+    shift, scale = rnd((1, D), gpu, 0.7, seed=184), rnd((1, D), gpu, 0.7, seed=185)
+    add = rnd((1, D), gpu, 0.5, seed=186) if with_add else None
+    splits = lib.drn_gemm_splitk_choice(rows, D, K)
+    assert splits > 1, "the shape must take the split-K path"
+    # reference: two launches
+    x_ref = x0.clone()
+    N.gemm(a, w, out=x_ref, epilogue=N.EPI_GATE_RES, gate=gate, residual=x_ref, rows_per_batch=rows)
+    h_ref = N.ln_modulate(x_ref, shift, scale, add_vec=add, rows_per_batch=rows)
+    # fused: slices only, then one pass
+    ws = torch.empty(lib.drn_gemm_splitk_workspace_bytes(rows, D, splits), dtype=torch.uint8, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    N._check(lib.drn_gemm_bf16_splitk_partials(a.data_ptr(), w.data_ptr(), rows, D, K, K, K, rows, splits, ws.data_ptr(), st), "partials")
+    x = x0.clone()
+    h = torch.empty_like(x)
+    N._check(lib.drn_splitk_gate_res_ln_modulate(ws.data_ptr(), splits, x.data_ptr(), gate.data_ptr(),
+                                                 add.data_ptr() if add is not None else None, shift.data_ptr(), scale.data_ptr(),
+                                                 h.data_ptr(), rows, D, rows, 1e-6, st), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_ref) and torch.equal(h, h_ref)
+
+
 def test_ln_modulate_with_broadcast_add(pkg, gpu):
     rows, D = 129, 512
     x = rnd((rows, D), gpu, 2.0, seed=20)
