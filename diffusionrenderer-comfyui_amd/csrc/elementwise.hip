@@ -342,7 +342,9 @@ extern "C" int drn_ln_modulate(void* x, const void* add_vec, const void* shift, 
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)((D + 511) / 512);
     // few rows: four waves per row (same bits as one wave per row: shared summation tree) - 4 x the waves in flight
-    const bool four = nch > 2 && rows < (1ll << 31) && (g_ln_force == 1 || (g_ln_force < 0 && rows <= 4096));
+    // (many rows, measured at 18432 x 4096 with tools/lnbench.py: without the pre-add 77-81 us one wave per row, 64-67 us four
+    //  waves per row; with it 82-95 vs 85-95 us: a draw, left on the one-wave kernel)
+    const bool four = nch > 2 && rows < (1ll << 31) && (g_ln_force == 1 || (g_ln_force < 0 && (rows <= 4096 || !add_vec)));
     dim3 grid(four ? (unsigned)rows : (unsigned)((rows + 3) / 4)), block(256);
 #define LAUNCH(K, N)                                                                                                  \
     K<N><<<grid, block, 0, st>>>((bf16_t*)x, (const bf16_t*)add_vec, (const bf16_t*)shift, (const bf16_t*)scale,      \
