@@ -43,7 +43,8 @@
 #include <stdlib.h>
 #include "drn_common.h"
 
-// G256S_ABL: timing-only ablation (results WRONG; shipped with 0): 8 = no epilogue math / stores
+// G256S_ABL: timing-only ablations (results WRONG; shipped with 0): 8 = no epilogue math / stores, 64 = no gate / residual loads,
+// 128 = no C stores (16 / 32: the hand-over waits, gemm256s_core.h)
 #ifndef G256S_ABL
 #define G256S_ABL 0
 #endif
@@ -56,10 +57,14 @@
 #define EPI_PARTIAL 3      // internal: split-K slice (blockIdx.y = slice), fp32 tile to the workspace, no epilogue
 
 // epilogue: column tiles nt = 0 / 1 exchanged between lane rows fq = 2k / 2k+1, 16-byte stores (16 per lane)
-template <int EPI>
+// PRE (gated-residual epilogue of whole tiles): the residual tile is already in LDS - row r of the tile at r * 512 B, its 16-byte
+// chunk c at chunk position c ^ (r & 15) - requested by the last two K steps in place of their re-requests (see the kernel); so
+// are the tile's 256 gate values (gate_lds: this wave's own copy)
+template <int EPI, bool PRE = false>
 static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf16_t* C, int64_t M, int64_t N, int64_t ldc,
                                                   const bf16_t* __restrict__ gate, const bf16_t* R, int64_t ldr, int64_t rpb,
-                                                  int cbc, int64_t cbs, int64_t m0, int64_t n0, int wr, int wc, int fr, int fq) {
+                                                  int cbc, int64_t cbs, int64_t m0, int64_t n0, int wr, int wc, int fr, int fq,
+                                                  const char* res_lds = nullptr, const char* gate_lds = nullptr) {
     if (G256S_ABL & 8) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -104,7 +109,30 @@ static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf
         // hipcc cannot move a load above the previous unit's store by itself).  Every element is loaded and stored by lanes of
         // the same wave (the permlane16 partner), and a wave's loads of a half all precede its stores of that half.
         uint2 g2[4][2][2], r2[4][2][2];
-        if (EPI == DRN_EPI_GATE_RES) {
+        if (EPI == DRN_EPI_GATE_RES && (G256S_ABL & 64)) {           // timing only: no gate / residual loads
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) g2[mt][j][nt] = r2[mt][j][nt] = make_uint2(0x3f803f80u, 0x3f803f80u);
+        } else if (EPI == DRN_EPI_GATE_RES && PRE) {
+            // whole tile, residual in LDS: (chunk ^ fr) for nt = 1 is that of nt = 0 with bit 1 flipped (bit 1 of wc*4 + (fq>>1) is 0)
+            const uint32_t ra = (uint32_t)((wr * 64 + fr) * 512 + (((wc * 4 + (fq >> 1)) ^ fr) << 4) + (fq & 1) * 8);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        r2[mt][j][nt] = *reinterpret_cast<const uint2*>(res_lds + i * 65536 + mt * 8192 + j * 256 + (ra ^ (nt * 32)));
+                        if (mt == 0) {                               // (a whole tile lies inside one clip: launcher)
+                            g2[0][j][nt] = *reinterpret_cast<const uint2*>(gate_lds + (j * 128 + wc * 32 + nt * 16 + fq * 4) * 2);
+                        } else {
+                            g2[mt][j][nt] = g2[0][j][nt];
+                        }
+                    }
+        } else if (EPI == DRN_EPI_GATE_RES) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int64_t m_raw = m0 + i * 128 + wr * 64 + mt * 16 + fr;
@@ -151,7 +179,9 @@ static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf
                 const auto sx = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
                 const auto sy = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
                 const int64_t n8 = n0 + j * 128 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
-                if (m_ok && n8 < N) {
+                if (G256S_ABL & 128) {                              // timing only: no stores
+                    asm volatile("" :: "v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]));
+                } else if (m_ok && n8 < N) {
                     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
                     const u32x4_t val = {sx[0], sy[0], sx[1], sy[1]};
                     u32x4_t* dst = reinterpret_cast<u32x4_t*>(C + m * ldc + n8 + c_tile_off);
@@ -164,7 +194,7 @@ static __device__ __forceinline__ void store_tile(f32x4_t (&acc)[2][4][2][2], bf
 }
 #define STORES_PER_TILE 16          // vector-memory stores per lane in store_tile (whole tiles): part of the vmcnt arithmetic
 
-template <int EPI>
+template <int EPI, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                           bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                                           int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
@@ -180,12 +210,87 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const bf16_t* __restri
     THREAD_SETUP();
     int64_t m0, n0;
     tile_of(blockIdx.x, nwg, tiles_m, tiles_n, GROUP, m0, n0);
+    const int k_second = min(1, nk - 1);
+    int kt = 0;
+    if (PRE) {
+        // Gated-residual epilogue of a whole tile (launcher: M, N multiples of 256, every tile inside one clip, nk even and >= 4).
+        // The last two K steps have nothing left to request, and the eight 16 KiB regions they free (stage 0 during step nk-2,
+        // stage 1 during step nk-1) are exactly one 256 x 256 bf16 tile: they request the RESIDUAL tile instead - same two 1 KiB
+        // pieces per wave and region, same wait counts - so that the epilogue finds it in LDS instead of starting 2 x 16 row-strided
+        // 8-byte loads per lane after the loop (measured: those loads were 11 % of the out-projection, 3.8 % of MLP-down;
+        // `G256S_ABL=64`).  Region q = 4 * stage + half-tile id holds rows 32 q .. 32 q + 31 of the tile (512 B each), a piece = 2
+        // rows, lane l = row l >> 5, chunk position l & 31.
+        // Whole tiles need no row clamp, so the operand pieces are addressed as a uniform half-tile base + ONE 32-bit lane offset per
+        // operand and piece (4 registers instead of the 8 lane pointers of the general kernel: the loop has none to spare).
+        (void)gsrc;
+        const char* abase = reinterpret_cast<const char*>(A + m0 * lda);
+        const char* wbase = reinterpret_cast<const char*>(W + n0 * ldw);
+        uint32_t voff[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = (wave * 2 + p) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            voff[0][p] = (uint32_t)((r * (int)lda + c * 8) * 2);
+            voff[1][p] = (uint32_t)((r * (int)ldw + c * 8) * 2);
+        }
+#undef DMA
+#define DMA(H, KD, S)                                                                                                  \
+    do {                                                                                                               \
+        const int kt_ = (int)(KD);                                                                                     \
+        char* dst_ = smem + H_OFF(S, H) + dma_off;                                                                     \
+        const char* sb_ = (H) < 2 ? abase + (((int64_t)((H) & 1) * 128 * lda + A_KOFF(kt_)) << 1)                      \
+                                  : wbase + (((int64_t)((H) & 1) * 128 * ldw + (int64_t)kt_ * BK) << 1);               \
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + voff[(H) >> 1][0]), (lptr_t)dst_, 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + voff[(H) >> 1][1]), (lptr_t)(dst_ + 1024), 16, 0, 0);          \
+    } while (0)
+        ZERO_ACC();
+        PROLOGUE();
+        for (; kt + 2 < nk; kt += 2) {
+            KSTEP(0, wx, wy, kt + 2, 10, 10, 10, 10);
+            KSTEP(1, wy, wx, kt + 3, 10, 10, 10, 10);
+        }
+        const char* rres = reinterpret_cast<const char*>(R + m0 * ldr + n0);
+        uint32_t roff[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rr = wave * 4 + p * 2 + (lane >> 5);           // row inside the region (its low 4 bits = those of the tile row)
+            roff[p] = (uint32_t)((rr * (int)ldr + (((lane & 31) ^ (rr & 15)) << 3)) * 2);
+        }
+#undef DMA
+#define DMA(H, KD, S)                                                                                                  \
+    do {                                                                                                               \
+        const char* rb_ = rres + (int64_t)(((S) * 4 + (H)) * 32) * ldr * 2;                                            \
+        char* dst_ = smem + ((S) * 4 + (H)) * HALF_BYTES + dma_off;                                                    \
+        __builtin_amdgcn_global_load_lds((gptr_t)(rb_ + roff[0]), (lptr_t)dst_, 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((gptr_t)(rb_ + roff[1]), (lptr_t)(dst_ + 1024), 16, 0, 0);                    \
+    } while (0)
+        KSTEP(0, wx, wy, 0, 10, 10, 10, 10);
+        // the tile's 256 gate values (512 B; every wave fetches its own copy, lanes 32..63 a second one: a piece is 1 KiB) ride along
+        // with the first request of the last step: one more piece in flight, so that step's hand-over waits count 11
+        const char* gbase = reinterpret_cast<const char*>(gate + (int64_t)((uint32_t)m0 / (uint32_t)rpb) * N + n0);
+        const uint32_t goff = (uint32_t)((lane & 31) * 16);
+        char* gate_lds = smem + 2 * STAGE_BYTES + wave * 1024;
+#undef DMA
+#define DMA(H, KD, S)                                                                                                  \
+    do {                                                                                                               \
+        const char* rb_ = rres + (int64_t)(((S) * 4 + (H)) * 32) * ldr * 2;                                            \
+        char* dst_ = smem + ((S) * 4 + (H)) * HALF_BYTES + dma_off;                                                    \
+        if ((H) == H_W0) __builtin_amdgcn_global_load_lds((gptr_t)(gbase + goff), (lptr_t)gate_lds, 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(rb_ + roff[0]), (lptr_t)dst_, 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((gptr_t)(rb_ + roff[1]), (lptr_t)(dst_ + 1024), 16, 0, 0);                    \
+    } while (0)
+        KSTEP(1, wy, wx, 0, 11, 11, 11, 11);
+#undef DMA
+#define DMA(H, KD, S) GEMM_DMA(H, KD, S)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the residual tile has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                                  // ... and everybody else's
+        store_tile<EPI, true>(acc, C, M, N, ldc, gate, R, ldr, rpb, cbc, cbs, m0, n0, wr, wc, fr, fq, smem, gate_lds);
+        return;
+    }
     SET_SRC(m0, n0);
     ZERO_ACC();
-    const int k_second = min(1, nk - 1);
     PROLOGUE();
     // steps past the end re-request the last one into a region nobody reads: the wait counts stay uniform
-    int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         KSTEP(0, wx, wy, min(kt + 2, nk - 1), 10, 10, 10, 10);
         KSTEP(1, wy, wx, min(kt + 3, nk - 1), 10, 10, 10, 10);
@@ -274,6 +379,16 @@ __global__ __launch_bounds__(512, 2) void gemm256w_kernel(const bf16_t* __restri
 #define A_OFF(S, I) ((S) * STAGE_BYTES + (I) * HALF_BYTES)
 #define W_OFF(S, J) ((S) * STAGE_BYTES + (2 + (J)) * HALF_BYTES)
 
+#ifndef G256S_PRE_DEFAULT
+#define G256S_PRE_DEFAULT 1
+#endif
+static int g_res_prefetch = G256S_PRE_DEFAULT;     // drn_gemm_force_res_prefetch (tests, A/B runs; tools/build_variants.py)
+extern "C" int drn_gemm_force_res_prefetch(int on) {
+    const int was = g_res_prefetch;
+    if (on >= 0) g_res_prefetch = on ? 1 : 0;
+    return was;
+}
+
 template <int EPI>
 static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                       int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
@@ -293,6 +408,29 @@ static int launch256s(const void* A, const void* W, void* C, int64_t M, int64_t 
         const char* e = getenv("DRN_GEMM_GROUP");          // tile-rows per L2 band (A/B experiments)
         group = e ? atoi(e) : 4;
         if (group < 1) group = 4;
+    }
+    if constexpr (EPI == DRN_EPI_GATE_RES) {
+        // whole tiles, each inside one clip, an even number (>= 4) of K steps, 16-byte residual rows: the residual tile comes in
+        // through LDS under the last two K steps (same bits: only where the epilogue reads it from changes)
+        static int pre = -1;
+        if (pre < 0) {
+            const char* e = getenv("DRN_GEMM_RES_PREFETCH");   // 0: the epilogue loads the residual itself (A/B runs, tests)
+            pre = (e && e[0] == '0') ? 0 : 1;
+            if (pre && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES + 8192) != hipSuccess) {
+                (void)hipGetLastError();
+                pre = 0;
+            }
+        }
+        const int64_t nk = K / BK;
+        if (pre && g_res_prefetch && M % TB == 0 && N % TB == 0 && rpb % TB == 0 && nk >= 4 && nk % 2 == 0 && residual && gate &&
+            ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)gate & 15) == 0 && 128 * ldr * 2 < (1ll << 31) && 128 * lda * 2 < (1ll << 31) &&
+            128 * ldw * 2 < (1ll << 31)) {
+            gemm256s_kernel<EPI, true><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES + 8192, st>>>(
+                (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
+                ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
+            return drn_launch_status();
+        }
     }
     gemm256s_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, st>>>(
         (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,

@@ -57,7 +57,8 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
 // blocked operand layouts (drn_gemm_bf16_blocked), see gemm256s.hip
 #define A_KOFF(KT) ((((int64_t)(KT) * BK) >> abc) * abs_ + (((int64_t)(KT) * BK) & ((1ll << abc) - 1)))
 // half-tile H of K step KD (of the tile gsrc points at) into stage S
-#define DMA(H, KD, S)                                                                                                  \
+#define DMA(H, KD, S) GEMM_DMA(H, KD, S)
+#define GEMM_DMA(H, KD, S)                                                                                             \
     do {                                                                                                               \
         const int kt_ = (int)(KD);                                                                                     \
         char* dst_ = smem + H_OFF(S, H) + dma_off;                                                                     \
@@ -74,11 +75,15 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
     acc[I][MT][J][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[NT][KS], af[MT][KS], acc[I][MT][J][NT], 0, 0, 0)
 // end of a group: the half-tile whose first read follows has landed (own pieces: 5 half-tiles = 10 younger pieces may fly;
 // VM = 10, or 10 + the stores of an epilogue that were issued after that half-tile's request)
+// (G256S_ABL, timing-only ablations with WRONG results: 16 = no counted DMA wait, 32 = no barrier)
+#ifndef G256S_ABL
+#define G256S_ABL 0
+#endif
 #define HANDOVER(VM)                                                                                                \
     do {                                                                                                            \
         FENCE();                                                                                                    \
-        asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                                      \
-        __builtin_amdgcn_s_barrier();                                                                               \
+        if (!(G256S_ABL & 16)) asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                               \
+        if (!(G256S_ABL & 32)) __builtin_amdgcn_s_barrier();                                                        \
         FENCE();                                                                                                    \
     } while (0)
 // one (mt, ks) slot of a group: the two MFMAs (nt = 0, 1) that read af[MT][KS], then that slot's share of the prefetch

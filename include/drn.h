@@ -90,6 +90,11 @@ int drn_gemm_splitk_choice(int64_t M, int64_t N, int64_t K);
  * A/B runs and tests (-1 = automatic). */
 int drn_gemm_tile_choice(int64_t M, int64_t N);
 void drn_gemm_force_tile(int tile);
+/* tuning hook (tests / A-B runs): the gated-residual epilogue of the 256x256 kernel takes its residual tile through LDS, requested
+ * under the last two K steps, when the launch allows it (whole tiles inside one clip, an even number >= 4 of K steps, 16-byte
+ * residual rows); 0 makes every launch load it after the loop as the other kernels do (same bits), 1 restores the default,
+ * -1 only queries.  Returns the previous setting.  (Environment: DRN_GEMM_RES_PREFETCH=0 disables it for the process.) */
+int drn_gemm_force_res_prefetch(int on);
 
 /* ---- weight-streaming GEMV family (batch-1 vectors: timestep MLP, AdaLN-LoRA, the 1-key cross-attention).
  * For g in [0,groups), b in [0,batch): y[g,b,:] = epi(W[g] . act(x[g,b,:]))   W[g]: [N,K] bf16

@@ -471,6 +471,57 @@ def test_gemm256_blocked_layouts(pkg, gpu):
     assert torch.equal(c_pl.permute(1, 0, 2).reshape(M, N), plain)
 
 
+@pytest.mark.parametrize("M,N,K,rpb,in_place", [(512, 512, 256, None, False), (2560, 4096, 4096, 1280, True),
+                                                 (18432, 4096, 512, 2304, True), (4608, 4096, 16384, None, False)])
+def test_gemm256_residual_prefetch_same_bits(pkg, gpu, M, N, K, rpb, in_place):
+    """The gated-residual epilogue with the residual tile requested into LDS under the last two K steps == the epilogue that loads
+    it after the loop, bit for bit (4 ... 256 K steps, several clips, C aliasing R), and == torch on the rounded linear."""
+    lib = pkg.native.load_library()
+    a, w = rnd((M, K), gpu, seed=150), rnd((N, K), gpu, K ** -0.5, seed=151)
+    B = M // rpb if rpb else 1
+    gate, res = rnd((B, N), gpu, seed=152), rnd((M, N), gpu, seed=153)
+    outs = []
+    lib.drn_gemm_force_tile(1)
+    try:
+        for on in (1, 0):
+            lib.drn_gemm_force_res_prefetch(on)
+            x = res.clone()
+            out = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=x, out=x if in_place else None,
+                                  rows_per_batch=rpb, splitk=1)
+            outs.append(out.clone())
+    finally:
+        lib.drn_gemm_force_tile(-1)
+        lib.drn_gemm_force_res_prefetch(1)
+    assert torch.equal(outs[0], outs[1])
+    lin = (a.float() @ w.float().t()).to(BF)
+    g = gate.repeat_interleave(M // B, dim=0)
+    ref = (res.float() + (g.float() * lin.float()).to(BF).float()).to(BF)
+    bad = (outs[0] != ref).float().mean().item()          # the fp32 product may round differently from torch's in a few places
+    assert bad < 2e-3, bad
+
+
+def test_gemm256_residual_prefetch_blocked_a(pkg, gpu):
+    """Same check with A stored as rank-major planes (the sequence-parallel output projection's operand layout)."""
+    lib = pkg.native.load_library()
+    M, N, K, P = 2304, 4096, 4096, 8
+    a, w = rnd((M, K), gpu, seed=160), rnd((N, K), gpu, K ** -0.5, seed=161)
+    gate, res = rnd((1, N), gpu, seed=162), rnd((M, N), gpu, seed=163)
+    a_pl = a.view(M, P, K // P).permute(1, 0, 2).contiguous()
+    outs = []
+    lib.drn_gemm_force_tile(1)
+    try:
+        for on in (1, 0):
+            lib.drn_gemm_force_res_prefetch(on)
+            x = res.clone()
+            pkg.native.gemm_blocked(a_pl, w, x, M, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=x, a_planes=True)
+            outs.append(x)
+        plain = pkg.native.gemm(a, w, epilogue=pkg.native.EPI_GATE_RES, gate=gate, residual=res)
+    finally:
+        lib.drn_gemm_force_tile(-1)
+        lib.drn_gemm_force_res_prefetch(1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], plain)
+
+
 @pytest.mark.parametrize("M,N,K,rpb", [(4352, 4096, 256, 2176), (18432, 4096, 512, None)])
 def test_gemm256_gated_residual_in_place(pkg, gpu, M, N, K, rpb):
     """Gated residual in place (C aliases R) on many rounds of tiles, also with a tile that straddles two clips
