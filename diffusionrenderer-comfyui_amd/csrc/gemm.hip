@@ -439,7 +439,7 @@ static int tall_choice(int64_t M, int64_t N, int64_t K) {
     if (tiles >= 192) return 1;
     // K slices only while a slice stays short (out-proj: 64 tiles x 4 slices of 16 K steps, 18 + 5 us against 21 + 9 on the
     // 128^2 path); with 64 K steps per slice every workgroup takes in a quarter of the A panel per slice and the 256^2 slices
-    // win (MLP-down: 58 + 5 us here against 43 + 9)
+    // win (MLP-down: 58 + 5 us here against 43 + 9; round 3, 128 x 128 tiles, 4 slices of 64 K steps: 59 us against 58 in all)
     for (int s = 2; s <= 8; s *= 2)
         if (tiles * s >= 192 && tiles * s <= 256 && (K / BK) % s == 0 && K / s >= 1024 && K / s <= 2048) return s;
     return 0;

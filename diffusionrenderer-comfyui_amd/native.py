@@ -63,6 +63,7 @@ SIGNATURES = {
     "drn_gemm_tile_choice": [_L, _L],
     "drn_gemm_force_tile": [_I],
     "drn_gemm_force_res_prefetch": [_I],
+    "drn_gemm_tall_force_shape": [_I],
     "drn_gemv_bf16": [_P, _P, _P, _L, _L, _I, _I, _L, _L, _L, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "drn_ln_modulate": [_P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
     "drn_ln_force_kernel": [_I],

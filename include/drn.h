@@ -95,6 +95,9 @@ void drn_gemm_force_tile(int tile);
  * residual rows); 0 makes every launch load it after the loop as the other kernels do (same bits), 1 restores the default,
  * -1 only queries.  Returns the previous setting.  (Environment: DRN_GEMM_RES_PREFETCH=0 disables it for the process.) */
 int drn_gemm_force_res_prefetch(int on);
+/* tuning hook (tests / A-B runs): tile of the few-token kernel (one clip of 256 rows), 0 = 256 rows x 64 columns, 1 = 128 x 128
+ * (same bits), -1 = the default (environment DRN_GEMM_TALL_SHAPE, else built in).  Returns the previous setting. */
+int drn_gemm_tall_force_shape(int shape);
 
 /* ---- weight-streaming GEMV family (batch-1 vectors: timestep MLP, AdaLN-LoRA, the 1-key cross-attention).
  * For g in [0,groups), b in [0,batch): y[g,b,:] = epi(W[g] . act(x[g,b,:]))   W[g]: [N,K] bf16

@@ -639,10 +639,18 @@ def test_gemm_splitk_weight_ring_kernel_equals_two_stage_kernel(pkg, gpu, M, N, 
     assert torch.equal(outs[-1], outs[4])
 
 
+@pytest.fixture(params=[0, 1], ids=["tall256x64", "tall128x128"])
+def tall_shape(request, pkg, gpu):
+    lib = pkg.native.load_library()
+    lib.drn_gemm_tall_force_shape(request.param)
+    yield request.param
+    lib.drn_gemm_tall_force_shape(-1)
+
+
 @pytest.mark.parametrize("N,K,epi", [(12288, 4096, 0), (16384, 4096, 1), (12288, 4096, 2), (4096, 4096, 2), (4096, 16384, 2),
                                      (12288, 192, 1), (16384, 64, 0)])
-def test_gemm_tall_kernel(pkg, gpu, N, K, epi):
-    """gemm_tall.hip (one clip of 256 rows; 256 x 64 tiles, 4-stage LDS ring, W and A three K steps ahead): unsplit it is
+def test_gemm_tall_kernel(pkg, gpu, N, K, epi, tall_shape):
+    """gemm_tall.hip (one clip of 256 rows; 256 x 64 tiles with a 4-stage LDS ring, or 128 x 128 tiles with 5 stages): unsplit it is
     bit-identical to the 128 x 128 kernel run unsplit (same K order per output element) for all three epilogues, in place for
     the gated residual; with K slices (N = 4096) within the usual bound of the fp32 product.  64, 256, 3 and 1 K steps."""
     lib = pkg.native.load_library()
@@ -667,6 +675,10 @@ def test_gemm_tall_kernel(pkg, gpu, N, K, epi):
         lib.drn_gemm_force_tile(-1)
     if splits == 1:
         assert torch.equal(got, plain)
+    else:                                            # the slices do not depend on the tile shape
+        lib.drn_gemm_tall_force_shape(1 - tall_shape)
+        assert torch.equal(got, run())
+        lib.drn_gemm_tall_force_shape(tall_shape)
     lin = (a.float() @ w.float().t()).to(BF)
     mag = None
     if epi == 0:

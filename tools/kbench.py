@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--Sk", type=int, default=0, help="keys for attention (default: S); S is then the local query/token count")
     ap.add_argument("--cold", type=int, default=1, help="gemm: rotate over this many copies of the weights (and activations) so that "
                     "they come from HBM, not from the 256 MB Infinity Cache, as inside the model (4-6 copies)")
+    ap.add_argument("--splitk", type=int, default=0, help="gemm: 1 = take the split-K path where drn_gemm_splitk_choice says so (few tokens)")
     ap.add_argument("--shapes", default="", help="attention: comma list of kernel bodies to time in one process (0 = 32x32x16, 1 = 16x16x32)")
     ap.add_argument("--diag", default="", help="attention: library built with -DATT_DIAG=1; prints the per-segment cycle shares")
     args = ap.parse_args()
@@ -77,6 +78,7 @@ def main():
                 cases.append(("attention Sq=%d Sk=%d body %s" % (S, Sk, ("32x32x16", "16x16x32")[sh]), run_shape, fl))
         else:
             cases.append(("attention Sq=%d Sk=%d" % (S, Sk), run_attn, fl))
+    ws_box = [None]
     if "gemm" in args.what:
         a = rnd(S, D)
         for (Nn, K, epi, nm) in [(3 * D, D, 0, "qkv"), (D, D, 2, "out+gate"), (4 * D, D, 1, "mlp1+gelu"), (D, 4 * D, 2, "mlp2+gate")]:
@@ -95,9 +97,19 @@ def main():
                 turn[0] = (turn[0] + 1) % len(As)
                 A, Wt = As[turn[0]], Ws[turn[0]]
                 lib.drn_gemm_force_tile(tile)
-                rc = lib.drn_gemm_bf16(A.data_ptr(), Wt.data_ptr(), C.data_ptr(), S, Nn, K, K, K, Nn, epi,
-                                       gate.data_ptr() if gate is not None else None,
-                                       R.data_ptr() if R is not None else None, Nn, S, st)
+                splits = lib.drn_gemm_splitk_choice(S, Nn, K) if args.splitk else 1
+                if splits > 1:                                  # few tokens: the path native.gemm takes (slices + epilogue kernel)
+                    lib.drn_gemm_splitk_workspace_bytes.restype = ctypes.c_int64
+                    nb = lib.drn_gemm_splitk_workspace_bytes(S, Nn, splits)
+                    if ws_box[0] is None or ws_box[0].numel() < nb:
+                        ws_box[0] = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    rc = lib.drn_gemm_bf16_splitk(A.data_ptr(), Wt.data_ptr(), C.data_ptr(), S, Nn, K, K, K, Nn, epi,
+                                                  gate.data_ptr() if gate is not None else None,
+                                                  R.data_ptr() if R is not None else None, Nn, S, splits, ws_box[0].data_ptr(), st)
+                else:
+                    rc = lib.drn_gemm_bf16(A.data_ptr(), Wt.data_ptr(), C.data_ptr(), S, Nn, K, K, K, Nn, epi,
+                                           gate.data_ptr() if gate is not None else None,
+                                           R.data_ptr() if R is not None else None, Nn, S, st)
                 lib.drn_gemm_force_tile(-1)
                 assert rc == 0, rc
               cases.append((f"gemm {nm} [{S}x{K}]x[{Nn}x{K}] tile {tile}", run_gemm, 2.0 * S * Nn * K))
