@@ -146,17 +146,22 @@ def launch_ranks(n: int, argv) -> int:
     the marker line, not the code, identifies it.  A communicator is not reused after a failed collective, hence a FRESH run with
     DRN_SP_EXCHANGE=gather, and the relayed JSON line says so (`exchange_fallback`, `first_attempt_rc`).  Every other failure
     (a GPU fault, an assert, a kill) is relayed as it is, once, with the child's exit code; a child that outlives
-    DRN_BENCH_TIMEOUT_S (default 3000) is terminated (SIGTERM, then SIGKILL) and the launcher exits 124."""
+    DRN_BENCH_TIMEOUT_S (default 3000) is terminated (SIGTERM, then SIGKILL) and the launcher exits 124.
+    (A rendezvous port that was taken before torch.distributed.run could bind it - EADDRINUSE with no rank started - is not a run:
+    the command is issued again on a fresh port, at most twice, `rendezvous_port_retries` in the relayed line.)"""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     limit = float(os.environ.get("DRN_BENCH_TIMEOUT_S", "3000"))
     first_rc = None
-    for attempt in (0, 1):
+    attempt, port_retries = 0, 0
+    while attempt < 2:
+        # (test hook, tests/test_bench_launcher.py: DRN_BENCH_FIRST_PORT = a port the test keeps busy, used for the first try only)
+        hook_port = os.environ.get("DRN_BENCH_FIRST_PORT") if (attempt == 0 and port_retries == 0) else None
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+               "--master-port", hook_port or str(free_port()), os.path.abspath(__file__)] + list(argv)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            stdout, _ = proc.communicate(timeout=limit)
+            stdout, stderr = proc.communicate(timeout=limit)
         except subprocess.TimeoutExpired:
             # torch.distributed.run puts every rank in a session of its own, so a group kill of the launcher's child would
             # orphan them: SIGTERM first (its handler terminates the ranks it started), SIGKILL only if it does not return
@@ -171,6 +176,15 @@ def launch_ranks(n: int, argv) -> int:
                 proc.wait()
             print(f"[bench] {n}-rank run exceeded {limit:.0f} s: killed", file=sys.stderr, flush=True)
             return 124
+        sys.stderr.write(stderr)
+        sys.stderr.flush()
+        # the rendezvous port was taken between free_port() and torch.distributed.run's bind (no rank was started, nothing ran):
+        # the same command again on another port, at most twice, and the relayed line says so
+        if proc.returncode != 0 and not stdout.strip() and port_retries < 2 and \
+                ("EADDRINUSE" in stderr or "address already in use" in stderr.lower()):
+            port_retries += 1
+            print(f"[bench] rendezvous port in use before any rank started; retry {port_retries} on a fresh port", file=sys.stderr, flush=True)
+            continue
         line, probe_failed = None, False
         for ln in stdout.splitlines():
             t = ln.strip()
@@ -180,11 +194,14 @@ def launch_ranks(n: int, argv) -> int:
                 probe_failed = probe_failed or PROBE_MARKER in t
                 print(t, file=sys.stderr, flush=True)
         if line is not None and proc.returncode == 0:
-            if attempt == 1:
+            if attempt == 1 or port_retries:
                 rec = json.loads(line)
-                rec["exchange_fallback"] = True
-                rec["first_attempt_rc"] = first_rc
-                rec["retried_exchange"] = "gather"
+                if attempt == 1:
+                    rec["exchange_fallback"] = True
+                    rec["first_attempt_rc"] = first_rc
+                    rec["retried_exchange"] = "gather"
+                if port_retries:
+                    rec["rendezvous_port_retries"] = port_retries
                 line = json.dumps(rec)
             print(line, flush=True)
             return 0
@@ -192,6 +209,7 @@ def launch_ranks(n: int, argv) -> int:
             first_rc = proc.returncode
             print(f"[bench] all-to-all probe failed (rc {proc.returncode}); one fresh run with DRN_SP_EXCHANGE=gather", file=sys.stderr, flush=True)
             env["DRN_SP_EXCHANGE"] = "gather"
+            attempt = 1
             continue
         return proc.returncode or 1
     return 1

@@ -62,3 +62,19 @@ def test_probe_failure_with_gather_already_selected_is_not_retried():
 def test_hung_child_is_killed_at_the_limit():
     p = _run("--gpus", "2", "--dry-run", env={"DRN_DRYRUN_FAIL": "1:hang", "DRN_BENCH_TIMEOUT_S": "20"})
     assert p.returncode == 124 and not p.stdout.strip()
+
+
+def test_busy_rendezvous_port_is_retried_on_a_fresh_one():
+    # the port handed to torch.distributed.run is taken (here: by this test) before it can bind: no rank ever starts; the launcher
+    # issues the same command again on another port and says so in the relayed line
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        sk.listen(1)
+        p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", env={"DRN_BENCH_FIRST_PORT": str(sk.getsockname()[1])})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stderr.count("rendezvous port in use") == 1 and "one fresh run" not in p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["rendezvous_port_retries"] == 1 and "exchange_fallback" not in rec

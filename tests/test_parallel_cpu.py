@@ -4,7 +4,6 @@ multi-GPU design rests on: every op but self-attention is token-local, the K/V b
 token order, RoPE rows are offset by the band start, and the gathered output rows unpatchify to the full latent.
 """
 import os
-import socket
 
 import pytest
 import torch
@@ -15,12 +14,18 @@ import torch.nn.functional as F
 from conftest import ROOT, tiny_net
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+_RDZV_N = [0]
+
+
+def _rdzv():
+    """A file:// rendezvous for the spawned ranks: no TCP port is picked ahead of time, so nothing else can take it in between
+    (a probed free port was found busy once on a GPU box: EADDRINUSE)."""
+    import tempfile
+    _RDZV_N[0] += 1
+    path = os.path.join(tempfile.gettempdir(), f"drn_rdzv_{os.getpid()}_{_RDZV_N[0]}")
+    if os.path.exists(path):
+        os.remove(path)
+    return "file://" + path
 
 
 def _sharded_forward(orc, O, par, x, t, cond, ci, group, exchange="gather"):
@@ -111,9 +116,8 @@ def _worker(rank, world, port, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         from __graft_entry__ import load_package
         from oracle import dit_oracle as O
@@ -159,7 +163,7 @@ def test_token_band_sharding_equals_unsharded_oracle():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _rdzv()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -183,9 +187,8 @@ def _bands_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         from __graft_entry__ import load_package
         par = load_package().parallel
@@ -214,7 +217,7 @@ def test_return_exchange_in_two_parts_equals_one_all_to_all(world):
     two uneven all-to-alls deliver exactly what the one equal-split all-to-all delivers."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _rdzv()
     procs = [ctx.Process(target=_bands_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -23,14 +23,27 @@ def _free_port():
     return p
 
 
+_RDZV_N = [0]
+
+
+def _rdzv():
+    """A file:// rendezvous for the spawned ranks: no TCP port is picked ahead of time, so nothing else can take it in between
+    (a probed free port was found busy once on a GPU box: EADDRINUSE)."""
+    import tempfile
+    _RDZV_N[0] += 1
+    path = os.path.join(tempfile.gettempdir(), f"drn_rdzv_{os.getpid()}_{_RDZV_N[0]}")
+    if os.path.exists(path):
+        os.remove(path)
+    return "file://" + path
+
+
 def _worker(rank, world, port, q, exchange, wide=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["DRN_SP_EXCHANGE"] = exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         from __graft_entry__ import load_package
         pkg = load_package()
@@ -90,7 +103,7 @@ def _worker(rank, world, port, q, exchange, wide=False):
 def test_sharded_hipdit_equals_single_rank(gpu, exchange, wide, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _rdzv()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, wide)) for r in range(world)]
     for p in procs:
         p.start()
@@ -108,11 +121,10 @@ def _rccl_worker(port, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=port, rank=0, world_size=1, device_id=dev)
     try:
         from __graft_entry__ import load_package
         pkg = load_package()
@@ -142,7 +154,7 @@ def test_exchange_paths_over_rccl_single_rank(gpu):
     device buffers, work.wait() stream ordering, workspace reuse over repeated forwards) and must not change a bit."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(_rdzv(), q))
     p.start()
     p.join(timeout=300)
     assert p.exitcode == 0
@@ -154,9 +166,8 @@ def _cond_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         from __graft_entry__ import load_package
         pkg = load_package()
@@ -192,7 +203,7 @@ def test_condition_encodes_spread_over_ranks(gpu):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _rdzv()
     procs = [ctx.Process(target=_cond_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -208,9 +219,8 @@ def _tok_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     try:
         from __graft_entry__ import load_package
         pkg = load_package()
@@ -241,7 +251,7 @@ def test_tokenizer_row_bands_equal_single_rank(gpu):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _rdzv()
     procs = [ctx.Process(target=_tok_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
