@@ -534,7 +534,7 @@ def main():
             # GEMM kernels' own rate)
             wbytes = 12.0 * 4096 * 4096 * 2 * args.blocks
             gbs = wbytes / (ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "gemm_bf16_kernel (split-K)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+            roofline = {"bound": "hbm", "kernel": "few-token linears (gemm_tall_kernel, gemm256w_kernel slices)", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
                         "note": "weight bytes of the executed linears / whole step time (no per-launch events at this size)"}
             if S >= 1024:
