@@ -22,6 +22,7 @@ import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -160,14 +161,28 @@ def launch_ranks(n: int, argv) -> int:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                "--master-port", hook_port or str(free_port()), os.path.abspath(__file__)] + list(argv)
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        err_lines, out_lines = [], []
+
+        def relay_stderr(pipe=proc.stderr, sink=err_lines):        # the ranks' stderr streams through as it comes (progress stays
+            for ln in pipe:                                        # visible during a long run); a copy is kept for the port check
+                sink.append(ln)
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+
+        def collect_stdout(pipe=proc.stdout, sink=out_lines):
+            for ln in pipe:
+                sink.append(ln)
+        readers = [threading.Thread(target=relay_stderr, daemon=True), threading.Thread(target=collect_stdout, daemon=True)]
+        for th in readers:
+            th.start()
         try:
-            stdout, stderr = proc.communicate(timeout=limit)
+            proc.wait(timeout=limit)
         except subprocess.TimeoutExpired:
             # torch.distributed.run puts every rank in a session of its own, so a group kill of the launcher's child would
             # orphan them: SIGTERM first (its handler terminates the ranks it started), SIGKILL only if it does not return
             proc.terminate()
             try:
-                proc.communicate(timeout=30)
+                proc.wait(timeout=30)
             except subprocess.TimeoutExpired:
                 try:
                     os.killpg(proc.pid, signal.SIGKILL)        # exactly the group this launcher started
@@ -176,8 +191,9 @@ def launch_ranks(n: int, argv) -> int:
                 proc.wait()
             print(f"[bench] {n}-rank run exceeded {limit:.0f} s: killed", file=sys.stderr, flush=True)
             return 124
-        sys.stderr.write(stderr)
-        sys.stderr.flush()
+        for th in readers:
+            th.join(timeout=10)
+        stdout, stderr = "".join(out_lines), "".join(err_lines)
         # the rendezvous port was taken between free_port() and torch.distributed.run's bind (no rank was started, nothing ran):
         # the same command again on another port, at most twice, and the relayed line says so
         if proc.returncode != 0 and not stdout.strip() and port_retries < 2 and \
