@@ -5,6 +5,10 @@
 #pragma once
 #include "drn_common.h"
 
+// (G256S_ABL, timing-only ablations with WRONG results: 16 = no counted DMA wait, 32 = no barrier, 256 = half of the fragment reads)
+#ifndef G256S_ABL
+#define G256S_ABL 0
+#endif
 #define TB 256
 #define BK 64
 #define HALF_BYTES (128 * BK * 2)          // 16 KiB
@@ -67,18 +71,18 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][1] + ko_), (lptr_t)(dst_ + 1024), 16, 0, 0);                 \
     } while (0)
 
-#define LD_A(S, I, MT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + A_OFF(S, I) + ((KS) ? (offa ^ 64) : offa) + (MT) * 2048))
-#define LD_W(S, J, NT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + W_OFF(S, J) + ((KS) ? (offw ^ 64) : offw) + (NT) * 2048))
+#define LD_A_(S, I, MT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + A_OFF(S, I) + ((KS) ? (offa ^ 64) : offa) + (MT) * 2048))
+#define LD_W_(S, J, NT, KS) (*reinterpret_cast<const bf16x8_t*>(smem + W_OFF(S, J) + ((KS) ? (offw ^ 64) : offw) + (NT) * 2048))
+// (G256S_ABL & 256, timing only: every second A fragment and every second W fragment is NOT read - a third of the LDS read bytes gone,
+//  everything else unchanged: what the fragment reads cost in time at the chip's power limit)
+#define LD_A(S, I, MT, KS) (((G256S_ABL & 256) && ((MT) & 1)) ? af[(MT) & 2][KS] : LD_A_(S, I, MT, KS))
+#define LD_W(S, J, NT, KS) (((G256S_ABL & 256) && ((NT) & 1)) ? wx[0][KS] : LD_W_(S, J, NT, KS))
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MM(I, MT, J, NT, KS, WF)                                                                                    \
     acc[I][MT][J][NT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[NT][KS], af[MT][KS], acc[I][MT][J][NT], 0, 0, 0)
 // end of a group: the half-tile whose first read follows has landed (own pieces: 5 half-tiles = 10 younger pieces may fly;
 // VM = 10, or 10 + the stores of an epilogue that were issued after that half-tile's request)
-// (G256S_ABL, timing-only ablations with WRONG results: 16 = no counted DMA wait, 32 = no barrier)
-#ifndef G256S_ABL
-#define G256S_ABL 0
-#endif
 #define HANDOVER(VM)                                                                                                \
     do {                                                                                                            \
         FENCE();                                                                                                    \
