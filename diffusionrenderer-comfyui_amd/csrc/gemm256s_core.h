@@ -5,7 +5,7 @@
 #pragma once
 #include "drn_common.h"
 
-// (G256S_ABL, timing-only ablations with WRONG results: 16 = no counted DMA wait, 32 = no barrier, 256 = half of the fragment reads)
+// (G256S_ABL, timing-only ablations with WRONG results: 16 = no counted DMA wait, 32 = no barrier, 256 = half of the fragment reads, 512 = cached operands)
 #ifndef G256S_ABL
 #define G256S_ABL 0
 #endif
@@ -64,7 +64,8 @@ static __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, in
 #define DMA(H, KD, S) GEMM_DMA(H, KD, S)
 #define GEMM_DMA(H, KD, S)                                                                                             \
     do {                                                                                                               \
-        const int kt_ = (int)(KD);                                                                                     \
+        const int kt_ = (G256S_ABL & 512) ? 0 : (int)(KD);   /* (512, timing only: every request re-reads K step 0 - L2 hits) */ \
+        (void)0;                                                                                     \
         char* dst_ = smem + H_OFF(S, H) + dma_off;                                                                     \
         const int64_t ko_ = (H) < 2 ? A_KOFF(kt_) : (int64_t)kt_ * BK;                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[H][0] + ko_), (lptr_t)dst_, 16, 0, 0);                          \
