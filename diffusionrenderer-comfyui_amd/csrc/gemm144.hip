@@ -25,7 +25,8 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int EPI>
+// ONECLIP (gated-residual epilogue): the launcher vouches that no tile straddles two clips (rows_per_batch % 144 == 0 or one clip)
+template <int EPI, bool ONECLIP = false>
 __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          bf16_t* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                                                          int64_t ldw, int64_t ldc, const bf16_t* __restrict__ gate,
@@ -190,40 +191,71 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
     __syncthreads();                                     // every wave is past its last LDS read
 
     // ---- the two k-substep partial sums meet in LDS: G0 finishes columns nt 0,1 of its 64, G1 columns nt 2,3.
-    //      (static accumulator indices only: a run-time choice between acc[..][h] and acc[..][2+h] would send acc to scratch)
+    //      (static accumulator indices only - a run-time choice between acc[..][h] and acc[..][2+h] would send acc to scratch: G1 swaps
+    //      its halves under a uniform branch instead, see below)
     char* mine = smem + ((wn * 2 + grp) * 18) * 1024 + lane * 16;          // partner's contribution to MY tiles
     char* theirs = smem + ((wn * 2 + (grp ^ 1)) * 18) * 1024 + lane * 16;  // my contribution to the partner's tiles
-#define GIVE(OTHER)                                                                                     \
+#define GIVE()                                                                                          \
     do {                                                                                                \
         _Pragma("unroll") for (int mt = 0; mt < 9; ++mt)                                                \
             _Pragma("unroll") for (int h = 0; h < 2; ++h)                                               \
-                *reinterpret_cast<f32x4_t*>(theirs + (mt * 2 + h) * 1024) = acc[mt][(OTHER) + h];       \
+                *reinterpret_cast<f32x4_t*>(theirs + (mt * 2 + h) * 1024) = acc[mt][2 + h];       \
     } while (0)
-#define TAKE(OWN)                                                                                       \
+#define TAKE()                                                                                          \
     do {                                                                                                \
-        _Pragma("unroll") for (int mt = 0; mt < 9; ++mt)                                                \
+        _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                              \
             _Pragma("unroll") for (int h = 0; h < 2; ++h)                                               \
-                acc[mt][(OWN) + h] += *reinterpret_cast<const f32x4_t*>(mine + (mt * 2 + h) * 1024);    \
+                acc[mt][h] += *reinterpret_cast<const f32x4_t*>(mine + (mt * 2 + h) * 1024);    \
+            if (mt % 2 == 1 || mt == 8) {     /* 4 reads in flight, not 18 (the residual registers are live): the sums are formed HERE */ \
+                _Pragma("unroll") for (int m3 = (mt == 8 ? 8 : mt - 1); m3 <= mt; ++m3)                 \
+                    asm volatile("" : "+v"(acc[m3][0]), "+v"(acc[m3][1]));                  \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+            }                                                                                           \
+        }                                                                                               \
     } while (0)
     // epilogue of the owned tiles: lane holds C[m][n..n+3] of both; the two column tiles are exchanged between lane rows
     // fq = 2k / 2k+1 (v_permlane16_swap) so that a lane stores 8 consecutive outputs, 16 B (see gemm256s.hip)
-#define STORE_TILES(OWN)                                                                                \
+    // gate / residual of the owned tiles: all 9 row tiles' loads in flight at once, requested right after this wave gave its other
+    // half away (those 72 accumulator registers are free) so that their latency runs under the barrier and the LDS exchange; issued
+    // per row tile in front of its store they were 9 dependent memory round trips (the residual may alias C: hipcc cannot move a
+    // load above the previous store).  Every element is loaded and stored by lanes of the same wave (the permlane16 partner).
+    uint2 g1_[2], r2_[9][2];
+    const int64_t b_tile = (EPI == DRN_EPI_GATE_RES) ? (int64_t)((uint32_t)m0 / (uint32_t)rpb) : 0;     // launcher: M < 2^31
+    constexpr bool one_clip = ONECLIP;                                // the tile lies inside one clip: one gate row
+#define LOAD_RES(OWN)                                                                                   \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (EPI == DRN_EPI_GATE_RES && one_clip) {                                                      \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h)                                               \
+                g1_[h] = *reinterpret_cast<const uint2*>(gate + b_tile * N + n0 + wn * 64 + ((OWN) + h) * 16 + fq * 4); \
+            /* a uniform base + 32-bit lane offsets (launcher: 144 rows x ldr x 2 B < 2^31): no 64-bit address per row tile */ \
+            const char* rb_ = reinterpret_cast<const char*>(R + m0 * ldr + n0 + wn * 64 + (OWN) * 16);  \
+            const int last_ = (int)min((int64_t)(TM - 1), M - 1 - m0);                                  \
+            _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                          \
+                const uint32_t ro_ = (uint32_t)((min(mt * 16 + fr, last_) * (int)ldr + fq * 4) * 2);    \
+                _Pragma("unroll") for (int h = 0; h < 2; ++h)                                           \
+                    r2_[mt][h] = *reinterpret_cast<const uint2*>(rb_ + ro_ + h * 32);                   \
+            }                                                                                           \
+        }                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+    // PRE = 1: gate / residual come from g1_ / r2_ (tile inside one clip); 0: loaded per row tile (a tile that straddles two clips)
+#define STORE_TILES(OWN, PRE)                                                                           \
     do {                                                                                                \
         _Pragma("unroll") for (int mt = 0; mt < 9; ++mt) {                                              \
             const int64_t m_raw = m0 + mt * 16 + fr;                                                    \
             const bool m_ok = m_raw < M;                                                                \
             const int64_t m = m_ok ? m_raw : M - 1;                                                     \
-            const int64_t b = (EPI == DRN_EPI_GATE_RES) ? m / rpb : 0;                                  \
             uint2 o[2];                                                                                 \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                             \
-                const int64_t n = n0 + wn * 64 + ((OWN) + h) * 16 + fq * 4;                             \
                 float v[4];                                                                             \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = rbf(acc[mt][(OWN) + h][r]);        \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = rbf(acc[mt][h][r]);        \
                 if (EPI == DRN_EPI_GELU) {                                                              \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);           \
                 } else if (EPI == DRN_EPI_GATE_RES) {                                                   \
-                    const uint2 g2 = *reinterpret_cast<const uint2*>(gate + b * N + n);                 \
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + m * ldr + n);                  \
+                    const int64_t n_ = n0 + wn * 64 + ((OWN) + h) * 16 + fq * 4;                        \
+                    const uint2 g2 = (PRE) ? g1_[h] : *reinterpret_cast<const uint2*>(gate + (int64_t)((uint32_t)m / (uint32_t)rpb) * N + n_); \
+                    const uint2 r2 = (PRE) ? r2_[mt][h] : *reinterpret_cast<const uint2*>(R + m * ldr + n_); \
                     const float g[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};                \
                     const float x[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};                \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = x[r] + rbf(g[r] * v[r]);       \
@@ -238,42 +270,63 @@ __global__ __launch_bounds__(512, 2) void gemm144_kernel(const bf16_t* __restric
                 *reinterpret_cast<uint4*>(C + m * ldc + n8 + c_tile_off) = make_uint4(sx[0], sy[0], sx[1], sy[1]); \
         }                                                                                               \
     } while (0)
-    if (grp == 0) {
-        GIVE(2);
-        __syncthreads();
-        TAKE(0);
-        STORE_TILES(0);
-    } else {
-        GIVE(0);
-        __syncthreads();
-        TAKE(2);
-        STORE_TILES(2);
+    // ONE code path for both groups: G1 swaps its halves first (72 v_swap, uniform branch), so that "own" is acc[..][0..1] and "given"
+    // acc[..][2..3] for every wave; which column tiles those are (own) only enters the addresses.  (Two copies of the epilogue, one per
+    // group, left the 72 registers of the half a wave has given away unused and spilled the residual instead.)
+    if (grp == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 9; ++mt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4_t t = acc[mt][h];
+                acc[mt][h] = acc[mt][2 + h];
+                acc[mt][2 + h] = t;
+            }
     }
+    const int own = grp * 2;
+    GIVE();
+    LOAD_RES(own);
+    __syncthreads();
+    TAKE();
+    STORE_TILES(own, ONECLIP);
+}
+
+template <int EPI, bool ONECLIP>
+static int launch144_k(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                       int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
+                       const int64_t* blk, int64_t tiles, int group) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm144_kernel<EPI, ONECLIP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    gemm144_kernel<EPI, ONECLIP><<<dim3((unsigned)tiles), dim3(512), NSTAGE * STAGE_BYTES, st>>>(
+        (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
+        ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
+    return drn_launch_status();
 }
 
 template <int EPI>
 static int launch144(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                      int64_t ldc, const void* gate, const void* residual, int64_t ldr, int64_t rpb, hipStream_t st,
                      const int64_t* blk) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm144_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
     const int64_t tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    if (tiles >= (1ll << 31)) return DRN_EINVAL;
+    if (tiles >= (1ll << 31) || M >= (1ll << 31)) return DRN_EINVAL;
+    if (rpb > M || rpb <= 0) rpb = M;                      // (32-bit row / rows_per_batch arithmetic in the epilogue)
     static int group = 0;
     if (group == 0) {
         const char* e = getenv("DRN_GEMM_GROUP");          // tile-rows per L2 band (A/B experiments)
         group = e ? atoi(e) : 4;
         if (group < 1) group = 4;
     }
-    gemm144_kernel<EPI><<<dim3((unsigned)tiles), dim3(512), NSTAGE * STAGE_BYTES, st>>>(
-        (const bf16_t*)A, (const bf16_t*)W, (bf16_t*)C, M, N, K, lda, ldw, ldc, (const bf16_t*)gate, (const bf16_t*)residual,
-        ldr, rpb, group, (int)blk[0], blk[1], (int)blk[2], blk[3]);
-    return drn_launch_status();
+    if constexpr (EPI == DRN_EPI_GATE_RES) {
+        // every tile inside one clip and 32-bit residual offsets: the epilogue that requests the residual before the exchange
+        if ((rpb == M || rpb % TM == 0) && residual && (int64_t)TM * ldr * 2 < (1ll << 31))
+            return launch144_k<EPI, true>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, tiles, group);
+    }
+    return launch144_k<EPI, false>(A, W, C, M, N, K, lda, ldw, ldc, gate, residual, ldr, rpb, st, blk, tiles, group);
 }
 
 // called from drn_gemm_bf16 (gemm.hip) when 144-row tiles fill the CUs better than 256- or 128-row tiles
