@@ -138,8 +138,8 @@ class HipCosmosTokenizer:
             kp = _ceil(Pk, 64)
             o = torch.empty((T, P, C), dtype=BF, device=self.device)
             for f in range(T):                                        # one head of dim C per frame
-                s = V.dense_gemm(q[f], k[f].contiguous(), out_f32=True, alpha=scale)
-                p = V.softmax_rows(s, Pk, kp)
+                s = V.scores_f32(q[f], k[f].contiguous())            # raw fp32 scores; the softmax applies 1 / sqrt(C)
+                p = V.softmax_rows(s, Pk, kp, scale)
                 vt = V.transpose(v[f].contiguous(), kp)
                 if kp % 64 == 0 and C % 128 == 0:
                     N.gemm(p, vt, out=o[f])                           # P . V on the DiT's tile GEMM (bf16 out, fp32 accumulate)

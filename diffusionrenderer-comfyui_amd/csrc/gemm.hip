@@ -499,6 +499,17 @@ static int splitk_slices(const void* A, const void* W, int64_t M, int64_t N, int
     return drn_launch_status();
 }
 
+// C_f32[M, N] = A . W^T as it leaves the accumulators (no rounding, no epilogue): ONE "slice" of the streamed 256 x 256 kernel's
+// split-K form.  For products whose fp32 result feeds a softmax (the tokenizer's one-head spatial attention: 9216 x 9216 x 512 per
+// frame).  M, N multiples of 256, K a multiple of 64; same K order per output element as every other tile kernel here.
+extern "C" int drn_gemm_bf16_f32out(const void* A, const void* W, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                    void* stream) {
+    DRN_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0 && K % BK == 0);
+    DRN_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K);
+    DRN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0);
+    return drn_gemm256s_partial(A, W, C, M, N, K, lda, ldw, 1, stream, false);
+}
+
 // slices only: the caller sums them itself (drn_splitk_gate_res_ln_modulate folds the sum, the gated residual and the next
 // LayerNorm into one pass).  Same slices, bit for bit, as drn_gemm_bf16_splitk computes.
 extern "C" int drn_gemm_bf16_splitk_partials(const void* A, const void* W, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,

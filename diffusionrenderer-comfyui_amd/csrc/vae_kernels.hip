@@ -376,13 +376,14 @@ extern "C" int drn_resample(const void* x, void* y, int mode, int T, int H, int 
 
 // ------------------------------------------------------------------------------------------------ attention helpers
 // row softmax: fp32 scores [rows, ld] -> bf16 probabilities [rows, ldp] (columns >= n are written as zero up to ldp)
+// (scale: the scores are multiplied by it first - one fp32 product per element, the same one a GEMM epilogue with alpha = scale forms)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int n,
-                                                           int64_t ld, int64_t ldp) {
+                                                           int64_t ld, int64_t ldp, float scale) {
     const int64_t row = blockIdx.x;
     const float* sr = s + row * ld;
     __shared__ float red[4];
     float m = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, sr[i]);
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, sr[i] * scale);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -390,14 +391,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) sum += expf(sr[i] - m);
+    for (int i = threadIdx.x; i < n; i += 256) sum += expf(sr[i] * scale - m);
     sum = wave_sum(sum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
     sum = (red[0] + red[1]) + (red[2] + red[3]);
     const float inv = 1.0f / sum;
     bf16_t* pr = p + row * ldp;
-    for (int i = threadIdx.x; i < ldp; i += 256) pr[i] = i < n ? f2bf(expf(sr[i] - m) * inv) : (bf16_t)0;
+    for (int i = threadIdx.x; i < ldp; i += 256) pr[i] = i < n ? f2bf(expf(sr[i] * scale - m) * inv) : (bf16_t)0;
 }
 
 // the same softmax with the row held in registers: ONE read of the fp32 scores (the kernel above reads them three times - 1.0 GB per
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // sum is taken over a different partition of the row).
 template <int VPT>
 __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int n,
-                                                               int64_t ld, int64_t ldp) {
+                                                               int64_t ld, int64_t ldp, float scale) {
     const int64_t row = blockIdx.x;
     const float4* sr = reinterpret_cast<const float4*>(s + row * ld);
     const int nv = n >> 2;
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
         const int i = threadIdx.x + 256 * j;
         if (i < nv) {
             v[j] = sr[i];
+            v[j].x *= scale; v[j].y *= scale; v[j].z *= scale; v[j].w *= scale;
             m = fmaxf(fmaxf(m, fmaxf(v[j].x, v[j].y)), fmaxf(v[j].z, v[j].w));
         }
     }
@@ -452,18 +454,22 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
     for (int i = threadIdx.x + 256 * VPT; i < nvp; i += 256) pr[i] = make_uint2(0u, 0u);
 }
 
-extern "C" int drn_softmax_rows(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, void* stream) {
+extern "C" int drn_softmax_rows_scaled(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, float scale,
+                                       void* stream) {
     DRN_CHECK_ARG(scores && probs && rows >= 0 && n > 0 && ld >= n && ldp >= n && rows < (1ll << 31));
     if (rows == 0) return DRN_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = n % 4 == 0 && ld % 4 == 0 && ldp % 4 == 0 && ((uintptr_t)scores & 15) == 0 && ((uintptr_t)probs & 7) == 0;
-#define SM_LAUNCH(V) softmax_rows_reg_kernel<V><<<dim3((unsigned)rows), dim3(256), 0, st>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp)
+#define SM_LAUNCH(V) softmax_rows_reg_kernel<V><<<dim3((unsigned)rows), dim3(256), 0, st>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp, scale)
     if (vec && n <= 1024 * 4) SM_LAUNCH(4);
     else if (vec && n <= 1024 * 9) SM_LAUNCH(9);          // 9216 keys: a 72 x 128 latent frame (the headline clip)
     else if (vec && n <= 1024 * 16) SM_LAUNCH(16);
-    else softmax_rows_kernel<<<dim3((unsigned)rows), dim3(256), 0, st>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp);
+    else softmax_rows_kernel<<<dim3((unsigned)rows), dim3(256), 0, st>>>((const float*)scores, (bf16_t*)probs, n, ld, ldp, scale);
 #undef SM_LAUNCH
     return drn_launch_status();
+}
+extern "C" int drn_softmax_rows(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, void* stream) {
+    return drn_softmax_rows_scaled(scores, probs, rows, n, ld, ldp, 1.0f, stream);
 }
 
 // transpose bf16 [rows, cols] -> [cols, ldo] (zero-filled beyond rows): V -> V^T for the P.V product

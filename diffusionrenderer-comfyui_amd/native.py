@@ -57,6 +57,7 @@ SIGNATURES = {
     "drn_gemm_bf16_blocked": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _L, _L, _L, _L, _P],
     "drn_gemm_bf16_splitk": [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P, _L, _L, _I, _P, _P],
     "drn_gemm_splitk_workspace_bytes": [_L, _L, _I],
+    "drn_gemm_bf16_f32out": [_P, _P, _P, _L, _L, _L, _L, _L, _P],
     "drn_gemm_bf16_splitk_partials": [_P, _P, _L, _L, _L, _L, _L, _L, _I, _P, _P],
     "drn_splitk_gate_res_ln_modulate": [_P, _I, _P, _P, _P, _P, _P, _P, _L, _L, _L, _F, _P],
     "drn_gemm_splitk_choice": [_L, _L, _L],

@@ -1,4 +1,5 @@
 """ctypes wrappers for the tokenizer entry points of include/drn.h (extends native.SIGNATURES)."""
+import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 import torch
@@ -20,6 +21,7 @@ N.SIGNATURES.update({
     "drn_haar_unpatch": [_P, _P, _I, _I, _I, _I, _I, _P],
     "drn_resample": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "drn_softmax_rows": [_P, _P, _L, _I, _L, _L, _P],
+    "drn_softmax_rows_scaled": [_P, _P, _L, _I, _L, _L, _F, _P],
     "drn_transpose_bf16": [_P, _P, _I, _I, _L, _L, _P],
     "drn_temporal_attention": [_P, _P, _P, _P, _I, _L, _I, _F, _P],
     "drn_planar_to_cl": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -205,12 +207,29 @@ def resample(x: CL, mode: int) -> CL:
     return out
 
 
-def softmax_rows(scores, n, ldp):
+def softmax_rows(scores, n, ldp, scale=1.0):
+    """bf16 softmax(scale * scores[:, :n]) per row, zero-filled up to ldp columns."""
     rows = scores.shape[0]
     probs = torch.empty((rows, ldp), dtype=BF, device=scores.device)
-    N._check(N.load_library().drn_softmax_rows(scores.data_ptr(), probs.data_ptr(), rows, n, scores.stride(0), ldp, N._stream()),
-             "drn_softmax_rows")
+    N._check(N.load_library().drn_softmax_rows_scaled(scores.data_ptr(), probs.data_ptr(), rows, n, scores.stride(0), ldp,
+                                                      float(scale), N._stream()), "drn_softmax_rows_scaled")
     return probs
+
+
+_SCORES_TILE = os.environ.get("DRN_VAE_SCORES_TILE", "1") != "0"      # 0: always the implicit-GEMM kernel (A/B runs)
+
+
+def scores_f32(q, k):
+    """fp32 q[M,K] @ k[N,K]^T as it leaves the accumulators: the 256 x 256 tile kernel when the shape allows (M, N % 256 == 0,
+    K % 64 == 0), else the implicit-GEMM kernel - same K order per element, same bits."""
+    M, K = q.shape
+    Nn = k.shape[0]
+    if _SCORES_TILE and M % 256 == 0 and Nn % 256 == 0 and K % 64 == 0 and q.is_contiguous() and k.is_contiguous():
+        out = torch.empty((M, Nn), dtype=torch.float32, device=q.device)
+        N._check(N.load_library().drn_gemm_bf16_f32out(q.data_ptr(), k.data_ptr(), out.data_ptr(), M, Nn, K, K, K, N._stream()),
+                 "drn_gemm_bf16_f32out")
+        return out
+    return dense_gemm(q, k, out_f32=True)
 
 
 def transpose(x, ldo):

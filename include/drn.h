@@ -80,6 +80,10 @@ int drn_gemm_bf16_splitk(const void* A, const void* W, void* C, int64_t M, int64
                          const void* gate, const void* residual, int64_t ldr, int64_t rows_per_batch,
                          int splits, void* workspace, void* stream);
 int64_t drn_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
+/* C_f32[M, N] = A . W^T in fp32 as it leaves the accumulators (M, N multiples of 256, K of 64; 256 x 256 streamed kernel): products
+ * whose result feeds a softmax - the tokenizer's one-head spatial attention (CleanVAE.py:50-60 -> diffusers' mid-block attention). */
+int drn_gemm_bf16_f32out(const void* A, const void* W, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, void* stream);
+
 /* the K slices alone: fp32 partials [splits][M][N] in `workspace`, no sum, no epilogue (the same slices, bit for bit) */
 int drn_gemm_bf16_splitk_partials(const void* A, const void* W, int64_t M, int64_t N, int64_t K,
                                   int64_t lda, int64_t ldw, int64_t rows_per_batch, int splits, void* workspace, void* stream);
@@ -307,6 +311,8 @@ int drn_resample(const void* x, void* y, int mode, int T, int H, int W, int C, i
 
 /* ---- mid-block attention pieces (1 head of dim C): fp32 row softmax -> bf16, bf16 transpose, causal temporal attention */
 int drn_softmax_rows(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, void* stream);
+/* the same with the scores multiplied by `scale` first (one fp32 product per element: what a GEMM epilogue with alpha = scale forms) */
+int drn_softmax_rows_scaled(const void* scores, void* probs, int64_t rows, int n, int64_t ld, int64_t ldp, float scale, void* stream);
 int drn_transpose_bf16(const void* x, void* y, int rows, int cols, int64_t ldx, int64_t ldo, void* stream);
 int drn_temporal_attention(const void* q, const void* k, const void* v, void* o, int T, int64_t P, int C, float scale,
                            void* stream);

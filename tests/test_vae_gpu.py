@@ -178,6 +178,22 @@ def test_dense_gemm_softmax_transpose(pkg, gpu):
     assert rel_l2(o, p.float()[:, :100] @ v.float()) < 3e-3
 
 
+@pytest.mark.parametrize("P,C", [(2304, 512), (512, 128), (9216, 512)])
+def test_scores_on_the_tile_gemm_equal_the_implicit_gemm_path(pkg, gpu, P, C):
+    """Spatial attention of the mid block: raw fp32 scores from the 256 x 256 tile kernel (drn_gemm_bf16_f32out) + a softmax that
+    applies the scale == scores scaled in the implicit-GEMM epilogue + plain softmax, bit for bit (same K order per element, the
+    same fp32 product scale * score); ragged shapes keep the old kernel."""
+    V = pkg.native_vae
+    q, k = rnd((P, C), seed=40).to(gpu), rnd((P, C), seed=41).to(gpu)
+    scale = C ** -0.5
+    s_old = V.dense_gemm(q, k, out_f32=True, alpha=scale)
+    s_new = V.scores_f32(q, k)
+    assert torch.equal(s_new * scale, s_old)
+    assert torch.equal(V.softmax_rows(s_new, P, P, scale), V.softmax_rows(s_old, P, P))
+    qr, kr = q[:200].contiguous(), k[:300].contiguous()              # not multiples of 256: the implicit-GEMM kernel
+    assert torch.equal(V.scores_f32(qr, kr), V.dense_gemm(qr, kr, out_f32=True))
+
+
 @pytest.mark.parametrize("n,ldp", [(100, 128), (2304, 2304), (4100, 4160), (9216, 9216), (16384, 16384), (16388, 16448), (4098, 4160)])
 def test_softmax_rows_register_and_three_pass_kernels(pkg, gpu, n, ldp):
     """drn_softmax_rows: rows of up to 4096 / 9216 / 16384 scores stay in registers (one read of the fp32 scores), longer or
